@@ -1,0 +1,575 @@
+// hrt_device.h — device-side restatement of the reference's hit / scatter /
+// texture code over the FLATTENED scene (no virtual dispatch, no pointers to
+// objects): one function per reference method, cited at each definition.
+//
+// Arithmetic rule: every value that reaches a hitRecord, a scattered ray or a
+// pixel is computed with the same IEEE operations in the same order as the
+// reference lines cited (and therefore as oracle/oracle.cpp), with
+// -ffp-contract=off.  The only place that is free to differ is BVH *culling*
+// (bvh_traverse): a culled box can only remove triangles the reference would
+// also have rejected, because the final acceptance of a candidate uses the
+// reference's own leaf-level box test (accept_box below).
+#pragma once
+#include "hrt_rng.h"
+#include "../../include/hrt.h"
+
+namespace hrt {
+
+#define HRT_STACK_DEPTH 32
+#define HRT_BLOCK 256
+
+struct DScene {
+    const hrt_prim* prims;
+    const hrt_material* mats;
+    const hrt_texture* texs;
+    const hrt_mesh* meshes;
+    const float4* nodes;     // 4 x float4 per node (hrt_bvh_node)
+    const float4* tri_pos;   // 3 x float4 per triangle: v0.xyz_, v1.xyz_, v2.xyz_
+    const float4* tri_attr;  // 4 x float4 per triangle: n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y _
+    const float4* tri_box;   // 2 x float4 per triangle: reference leaf-level box (min.xyz_, max.xyz_)
+    const uint8_t* texels_u8;
+    const float* texels_f32;
+    int32_t n_prims;
+    int32_t background_tex;
+};
+
+struct DRec {  // hitRecord (hittable.h:8-25)
+    vec3 p, normal;
+    float t, u, v;
+    int32_t mat;
+    bool frontFace;
+};
+
+struct DCounters {
+    uint32_t box_tests, tri_tests;
+};
+
+__device__ inline void set_face_normal(DRec& rec, vec3 rdir, vec3 outward) {  // hittable.h:21-24
+    rec.frontFace = dot(rdir, outward) < 0;
+    rec.normal = rec.frontFace ? outward : -outward;
+}
+
+// ------------------------------------------------------------------ wrappers (ray side)
+// translate.cpp:9, scale.cpp:13-16, rotateQuat.cpp:47-52, rotateY.cpp:46-54
+__device__ inline void xf_apply(const hrt_xform& x, vec3& o, vec3& d, uint32_t quirks) {
+    if (x.kind == HRT_XF_TRANSLATE) {
+        o = o - vec3(x.v[0], x.v[1], x.v[2]);
+    } else if (x.kind == HRT_XF_SCALE) {
+        vec3 f(x.v[0], x.v[1], x.v[2]);
+        o = o / f; d = d / f;
+    } else if (x.kind == HRT_XF_ROTATE_QUAT) {
+        quat q; q.x = x.v[0]; q.y = x.v[1]; q.z = x.v[2]; q.w = x.v[3];
+        quat inv = conjugate(q);
+        o = rotate(inv, o);
+        d = rotate(inv, d);
+        if (quirks & HRT_Q1_ROTQ_NORMALIZE) d = normalize(d);
+    } else {
+        float s = x.v[0], c = x.v[1];
+        vec3 o2 = o, d2 = d;
+        o2.x = c * o.x - s * o.z; o2.z = s * o.x + c * o.z;
+        d2.x = c * d.x - s * d.z; d2.z = s * d.x + c * d.z;
+        o = o2; d = d2;
+    }
+}
+// record side: translate.cpp:15-16, scale.cpp:23-24, rotateQuat.cpp:60-63, rotateY.cpp:61-73
+// `ldir` = direction of the ray this wrapper handed to its child.
+__device__ inline void xf_unapply(const hrt_xform& x, DRec& rec, vec3 ldir) {
+    if (x.kind == HRT_XF_TRANSLATE) {
+        rec.p = rec.p + vec3(x.v[0], x.v[1], x.v[2]);
+        set_face_normal(rec, ldir, rec.normal);
+    } else if (x.kind == HRT_XF_SCALE) {
+        rec.p = rec.p * vec3(x.v[0], x.v[1], x.v[2]);
+        set_face_normal(rec, ldir, rec.normal);
+    } else if (x.kind == HRT_XF_ROTATE_QUAT) {
+        quat q; q.x = x.v[0]; q.y = x.v[1]; q.z = x.v[2]; q.w = x.v[3];
+        rec.p = rotate(q, rec.p);
+        rec.normal = rotate(q, rec.normal);
+        set_face_normal(rec, ldir, rec.normal);
+    } else {
+        float s = x.v[0], c = x.v[1];
+        vec3 p = rec.p, n = rec.normal;
+        p.x = c * rec.p.x + s * rec.p.z; p.z = -s * rec.p.x + c * rec.p.z;
+        n.x = c * rec.normal.x + s * rec.normal.z; n.z = -s * rec.normal.x + c * rec.normal.z;
+        rec.p = p;
+        set_face_normal(rec, ldir, n);
+    }
+}
+
+// ------------------------------------------------------------------ analytic primitives
+// aarect.h:12-39 / 59-86 / 106-133.  `axis` = the constant axis (0:YZ, 1:XZ, 2:XY).
+// p = a0,a1,b0,b1,k in the reference's member order.
+__device__ inline bool rect_hit(int axis, const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
+    float ok, dk, oa, da, ob, db;
+    if (axis == 0) { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
+    else if (axis == 1) { ok = o.y; dk = d.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
+    else { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+    float t = (p[4] - ok) / dk;
+    if (t < t_min || t > t_max) return false;
+    float a = oa + t * da;
+    float b = ob + t * db;
+    if (a < p[0] || a > p[1] || b < p[2] || b > p[3]) return false;
+    t_out = t;
+    return true;
+}
+__device__ inline void rect_rec(int axis, const float* p, vec3 o, vec3 d, float t, DRec& rec) {
+    float oa, da, ob, db;
+    if (axis == 0) { oa = o.y; da = d.y; ob = o.z; db = d.z; }
+    else if (axis == 1) { oa = o.x; da = d.x; ob = o.z; db = d.z; }
+    else { oa = o.x; da = d.x; ob = o.y; db = d.y; }
+    float a = oa + t * da;
+    float b = ob + t * db;
+    rec.u = (a - p[0]) / (p[1] - p[0]);
+    rec.v = (b - p[2]) / (p[3] - p[2]);
+    rec.t = t;
+    vec3 n = axis == 0 ? vec3(1, 0, 0) : (axis == 1 ? vec3(0, 1, 0) : vec3(0, 0, 1));
+    set_face_normal(rec, d, n);
+    rec.p = o + (t * d);
+}
+__device__ inline int rect_axis(int kind) { return kind == HRT_PRIM_YZ_RECT ? 0 : (kind == HRT_PRIM_XZ_RECT ? 1 : 2); }
+
+// sphere.cpp:20-36
+__device__ inline bool sphere_hit(const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
+    vec3 center(p[0], p[1], p[2]);
+    float radius = p[3];
+    vec3 oc = o - center;
+    float a = length(d) * length(d);
+    float half_b = dot(oc, d);
+    float c = length(oc) * length(oc) - radius * radius;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return false;
+    float sqrtd = sqrtf(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+// sphere.cpp:38-46 + getSphereUV (sphere.cpp:4-18)
+__device__ inline void sphere_rec(const float* p, vec3 o, vec3 d, float t, DRec& rec) {
+    const float pi = 3.14159265358979323846264338327950288f;
+    vec3 center(p[0], p[1], p[2]);
+    rec.t = t;
+    rec.p = o + (t * d);
+    vec3 outward = (rec.p - center) / p[3];
+    set_face_normal(rec, d, outward);
+    float theta = gacos(-outward.y);
+    float phi = gatan2(-outward.z, outward.x) + pi;
+    rec.u = phi / (2 * pi);
+    rec.v = theta / pi;
+}
+
+// box.h:27-55: six rects in constructBox order, HittableList::hit semantics.
+__device__ inline void box_side(const float* p, int side, int& axis, float* rp) {
+    // p = min.xyz, max.xyz
+    if (side < 2) { axis = 2; rp[0] = p[0]; rp[1] = p[3]; rp[2] = p[1]; rp[3] = p[4]; rp[4] = side == 0 ? p[5] : p[2]; }
+    else if (side < 4) { axis = 1; rp[0] = p[0]; rp[1] = p[3]; rp[2] = p[2]; rp[3] = p[5]; rp[4] = side == 2 ? p[4] : p[1]; }
+    else { axis = 0; rp[0] = p[1]; rp[1] = p[4]; rp[2] = p[2]; rp[3] = p[5]; rp[4] = side == 4 ? p[3] : p[0]; }
+}
+__device__ inline bool box_hit(const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t_out, int& side_out) {
+    bool any = false;
+    float closest = t_max;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        int axis; float rp[5];
+        box_side(p, s, axis, rp);
+        float t;
+        if (rect_hit(axis, rp, o, d, t_min, closest, t)) { any = true; closest = t; side_out = s; }
+    }
+    t_out = closest;
+    return any;
+}
+__device__ inline void box_rec(const float* p, vec3 o, vec3 d, float t, int side, DRec& rec) {
+    int axis; float rp[5];
+    box_side(p, side, axis, rp);
+    rect_rec(axis, rp, o, d, t, rec);
+}
+
+__device__ inline bool boundary_hit(int kind, const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t) {
+    int side;
+    if (kind == HRT_PRIM_SPHERE) return sphere_hit(p, o, d, t_min, t_max, t);
+    return box_hit(p, o, d, t_min, t_max, t, side);
+}
+// constantMedium.cpp:4-38
+__device__ inline bool medium_hit(const hrt_prim& pr, uint32_t prim_index, vec3 o, vec3 d, float t_min, float t_max,
+                                  const rng_ctx& ctx, float& t_out) {
+    const float INF = __builtin_huge_valf();
+    float t1, t2;
+    if (!boundary_hit(pr.boundary_kind, pr.p, o, d, -INF, INF, t1)) return false;
+    if (!boundary_hit(pr.boundary_kind, pr.p, o, d, t1 + 0.0001f, INF, t2)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0) t1 = 0;
+    const float ray_length = length(d);
+    const float distance_inside_boundary = (t2 - t1) * ray_length;
+    u32x4 u = rng_draw(ctx, RNG_MEDIUM, prim_index);
+    const float negInvDensity = -1 / pr.density;
+    const float hit_distance = negInvDensity * glog(linear_rand(u.x, 0.0f, 1.0f));
+    if (hit_distance > distance_inside_boundary) return false;
+    t_out = t1 + hit_distance / ray_length;
+    return true;
+}
+
+// ------------------------------------------------------------------ ITriangle::hit (triangle.cpp:57-131)
+struct TriRay {          // per-ray constants of the triangle test
+    vec3 o;
+    float sX, sY, sZ;
+    int kZ;
+};
+__device__ inline TriRay tri_ray_setup(vec3 o, vec3 d, uint32_t quirks) {
+    TriRay tr;
+    tr.o = o;
+    int kZ;
+    if (quirks & HRT_Q4_SHEAR_FROM_ORIGIN) {
+        kZ = o.x > o.z ? (o.x > o.y ? 0 : 1) : 2;  // triangle.cpp:70
+    } else {
+        float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+        kZ = ax > ay ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+    }
+    tr.kZ = kZ;
+    // d = { d[kX], d[kY], d[kZ] }
+    float dx = kZ == 2 ? d.x : (kZ == 0 ? d.y : d.z);
+    float dy = kZ == 2 ? d.y : (kZ == 0 ? d.z : d.x);
+    float dz = kZ == 2 ? d.z : (kZ == 0 ? d.x : d.y);
+    tr.sX = -dx / dz;
+    tr.sY = -dy / dz;
+    tr.sZ = 1.0f / dz;
+    return tr;
+}
+__device__ inline vec3 tri_permute(vec3 v, int kZ) {
+    return vec3(kZ == 2 ? v.x : (kZ == 0 ? v.y : v.z), kZ == 2 ? v.y : (kZ == 0 ? v.z : v.x),
+                kZ == 2 ? v.z : (kZ == 0 ? v.x : v.y));
+}
+struct TriEval { float e0, e1, e2, det, tScaled; };
+// triangle.cpp:64-105.  Returns false on the edge / determinant rejections.
+__device__ inline bool tri_eval(const TriRay& tr, vec3 v0, vec3 v1, vec3 v2, TriEval& ev) {
+    vec3 p0t = tri_permute(v0 - tr.o, tr.kZ);
+    vec3 p1t = tri_permute(v1 - tr.o, tr.kZ);
+    vec3 p2t = tri_permute(v2 - tr.o, tr.kZ);
+    p0t.x = p0t.x + tr.sX * p0t.z; p0t.y = p0t.y + tr.sY * p0t.z;
+    p1t.x = p1t.x + tr.sX * p1t.z; p1t.y = p1t.y + tr.sY * p1t.z;
+    p2t.x = p2t.x + tr.sX * p2t.z; p2t.y = p2t.y + tr.sY * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z = p0t.z * tr.sZ; p1t.z = p1t.z * tr.sZ; p2t.z = p2t.z * tr.sZ;
+    ev.e0 = e0; ev.e1 = e1; ev.e2 = e2; ev.det = det;
+    ev.tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    return true;
+}
+// The leaf-level BVHNode::hit box test of the reference tree (aabb.h:26-39 on
+// the box of bvh.cpp:52-60), evaluated only for candidates that passed the
+// triangle test.
+__device__ inline bool accept_box(float4 bmn, float4 bmx, vec3 o, vec3 d, float t_min, float t_max) {
+    {
+        float ta = (bmn.x - o.x) / d.x, tb = (bmx.x - o.x) / d.x;
+        float t0 = (tb < ta) ? tb : ta; float t1 = (ta < tb) ? tb : ta;
+        t_min = (t_min < t0) ? t0 : t_min; t_max = (t1 < t_max) ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        float ta = (bmn.y - o.y) / d.y, tb = (bmx.y - o.y) / d.y;
+        float t0 = (tb < ta) ? tb : ta; float t1 = (ta < tb) ? tb : ta;
+        t_min = (t_min < t0) ? t0 : t_min; t_max = (t1 < t_max) ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        float ta = (bmn.z - o.z) / d.z, tb = (bmx.z - o.z) / d.z;
+        float t0 = (tb < ta) ? tb : ta; float t1 = (ta < tb) ? tb : ta;
+        t_min = (t_min < t0) ? t0 : t_min; t_max = (t1 < t_max) ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ Mesh::hit -> BVHNode::hit (mesh.cpp:43-46, bvh.cpp:69-78)
+// Flattened 2-wide BVH, per-lane stack in LDS (stack[depth][thread]: lanes of a
+// wave hit distinct banks whatever their depths).  Returns the closest
+// accepted triangle in [.., t_max] or -1.
+template <bool STATS>
+__device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 o, vec3 d, float t_min, float t_max,
+                                   uint32_t quirks, int* stack /* + threadIdx.x */, float& t_out, DCounters& cnt) {
+    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
+    const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
+    const TriRay tr = tri_ray_setup(o, d, quirks);
+    // culling-only constants (free to differ from the reference: see header)
+    const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;
+    const float ox = o.x * idx, oy = o.y * idy, oz = o.z * idz;
+    float closest = t_max;
+    int best = -1;
+    int sp = 0;
+    int cur = 0;  // root
+    const int SENTINEL = 0x7fffffff;
+    if (mesh.node_count == 0) cur = SENTINEL;
+    while (cur != SENTINEL) {
+        if (cur >= 0) {
+            const float4 n0 = nodes[4 * cur + 0];
+            const float4 n1 = nodes[4 * cur + 1];
+            const float4 n2 = nodes[4 * cur + 2];
+            const float4 n3 = nodes[4 * cur + 3];
+            if (STATS) cnt.box_tests += 2;
+            // child 0
+            float a0 = fmaf(n0.x, idx, -ox), a1 = fmaf(n0.y, idx, -ox);
+            float b0 = fmaf(n0.z, idy, -oy), b1 = fmaf(n0.w, idy, -oy);
+            float c0 = fmaf(n2.x, idz, -oz), c1 = fmaf(n2.y, idz, -oz);
+            float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_min));
+            float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), closest));
+            // child 1
+            float e0 = fmaf(n1.x, idx, -ox), e1 = fmaf(n1.y, idx, -ox);
+            float f0 = fmaf(n1.z, idy, -oy), f1 = fmaf(n1.w, idy, -oy);
+            float g0 = fmaf(n2.z, idz, -oz), g1 = fmaf(n2.w, idz, -oz);
+            float tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_min));
+            float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), closest));
+            const bool h0 = tn0 < tf0;   // aabb.h:35: t_max <= t_min rejects
+            const bool h1 = tn1 < tf1;
+            const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                const int nearc = swap ? ch1 : ch0, farc = swap ? ch0 : ch1;
+                stack[sp * HRT_BLOCK] = farc; ++sp;
+                cur = nearc;
+            } else if (h0) cur = ch0;
+            else if (h1) cur = ch1;
+            else if (sp > 0) { --sp; cur = stack[sp * HRT_BLOCK]; }
+            else cur = SENTINEL;
+        } else {
+            const uint32_t enc = (uint32_t)(~cur);
+            const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t ti = first + k;
+                const float4 q0 = tpos[3 * ti + 0], q1 = tpos[3 * ti + 1], q2 = tpos[3 * ti + 2];
+                if (STATS) cnt.tri_tests += 1;
+                TriEval ev;
+                if (!tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;
+                // triangle.cpp:106-109
+                if (ev.det < 0 && (ev.tScaled >= 0 || ev.tScaled < closest * ev.det)) continue;
+                else if (ev.det > 0 && (ev.tScaled <= 0 || ev.tScaled > closest * ev.det)) continue;
+                const float invDet = 1 / ev.det;
+                const float t = ev.tScaled * invDet;
+                if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
+                if (!accept_box(tbox[2 * ti], tbox[2 * ti + 1], o, d, t_min, closest)) continue;
+                closest = t;
+                best = (int)ti;
+            }
+            if (sp > 0) { --sp; cur = stack[sp * HRT_BLOCK]; }
+            else cur = SENTINEL;
+        }
+    }
+    t_out = closest;
+    return best;
+}
+
+// triangle.cpp:111-128 for the winning triangle
+__device__ inline void tri_rec(const DScene& sc, const hrt_mesh& mesh, int tri, vec3 o, vec3 d, uint32_t quirks, DRec& rec) {
+    const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
+    const float4* tattr = sc.tri_attr + 4ull * mesh.tri_first;
+    const TriRay tr = tri_ray_setup(o, d, quirks);
+    const float4 q0 = tpos[3 * tri + 0], q1 = tpos[3 * tri + 1], q2 = tpos[3 * tri + 2];
+    TriEval ev;
+    tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev);
+    float invDet = 1 / ev.det;
+    float b0 = ev.e0 * invDet;
+    float b1 = ev.e1 * invDet;
+    float b2 = ev.e2 * invDet;
+    float t = ev.tScaled * invDet;
+    rec.t = t;
+    rec.p = o + (t * d);
+    const float4 a0 = tattr[4 * tri + 0], a1 = tattr[4 * tri + 1], a2 = tattr[4 * tri + 2], a3 = tattr[4 * tri + 3];
+    vec3 normal = b0 * vec3(a0.x, a0.y, a0.z) + b1 * vec3(a1.x, a1.y, a1.z) + b2 * vec3(a2.x, a2.y, a2.z);
+    vec2 uv = b0 * vec2(a0.w, a1.w) + b1 * vec2(a2.w, a3.x) + b2 * vec2(a3.y, a3.z);
+    rec.normal = normal;
+    rec.u = uv.x;
+    rec.v = uv.y;
+    if (quirks & HRT_Q3_TRI_NO_FACE) rec.frontFace = true;
+    else set_face_normal(rec, d, normal);
+}
+
+// ------------------------------------------------------------------ world->hit (hittableList.cpp:4-21 over scene.cpp:376-379)
+struct WorldHit { int prim; int sub; float t; };  // sub = triangle index (mesh) or box side
+
+template <bool STATS>
+__device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_min, float t_max, uint32_t quirks,
+                                     const rng_ctx& ctx, int* stack, DCounters& cnt) {
+    WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = t_max;
+    float closest = t_max;
+    for (int i = 0; i < sc.n_prims; ++i) {
+        const hrt_prim& pr = sc.prims[i];
+        vec3 lo = o, ld = d;
+        for (int k = 0; k < pr.n_xforms; ++k) xf_apply(pr.xf[k], lo, ld, quirks);
+        float t; int sub = -1; bool hit;
+        const int kind = pr.kind;
+        if (kind == HRT_PRIM_MESH) {
+            sub = bvh_traverse<STATS>(sc, sc.meshes[pr.mesh], lo, ld, t_min, closest, quirks, stack, t, cnt);
+            hit = sub >= 0;
+        } else if (kind == HRT_PRIM_SPHERE) {
+            hit = sphere_hit(pr.p, lo, ld, t_min, closest, t);
+        } else if (kind == HRT_PRIM_BOX) {
+            hit = box_hit(pr.p, lo, ld, t_min, closest, t, sub);
+        } else if (kind == HRT_PRIM_MEDIUM) {
+            hit = medium_hit(pr, (uint32_t)i, lo, ld, t_min, closest, ctx, t);
+        } else {
+            hit = rect_hit(rect_axis(kind), pr.p, lo, ld, t_min, closest, t);
+        }
+        if (hit) { closest = t; wh.prim = i; wh.sub = sub; wh.t = t; }
+    }
+    return wh;
+}
+
+// Rebuilds the winner's hitRecord exactly as the reference's call chain does.
+__device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, DRec& rec) {
+    const hrt_prim& pr = sc.prims[wh.prim];
+    vec3 lo = o, ld = d;
+    vec3 dirs[HRT_MAX_XFORMS];
+    const int n = pr.n_xforms;
+#pragma unroll
+    for (int k = 0; k < HRT_MAX_XFORMS; ++k) {
+        if (k < n) { xf_apply(pr.xf[k], lo, ld, quirks); dirs[k] = ld; }
+    }
+    rec.mat = pr.material;
+    rec.frontFace = true;
+    const int kind = pr.kind;
+    if (kind == HRT_PRIM_MESH) tri_rec(sc, sc.meshes[pr.mesh], wh.sub, lo, ld, quirks, rec);
+    else if (kind == HRT_PRIM_SPHERE) sphere_rec(pr.p, lo, ld, wh.t, rec);
+    else if (kind == HRT_PRIM_BOX) box_rec(pr.p, lo, ld, wh.t, wh.sub, rec);
+    else if (kind == HRT_PRIM_MEDIUM) {  // constantMedium.cpp:30-36
+        rec.t = wh.t; rec.p = lo + (wh.t * ld); rec.normal = vec3(1, 0, 0); rec.frontFace = true; rec.u = 0.0f; rec.v = 0.0f;
+    } else rect_rec(rect_axis(kind), pr.p, lo, ld, wh.t, rec);
+#pragma unroll
+    for (int k = HRT_MAX_XFORMS - 1; k >= 0; --k) {
+        if (k < n) xf_unapply(pr.xf[k], rec, dirs[k]);
+    }
+}
+
+// ------------------------------------------------------------------ textures (texture.cpp)
+__device__ inline vec3 tex_leaf(const DScene& sc, const hrt_texture& t, float u, float v) {
+    if (t.kind == HRT_TEX_SOLID) return vec3(t.c[0], t.c[1], t.c[2]);
+    if (t.width == 0 || t.height == 0) return vec3(0, 1, 1);  // texture.cpp:56-57,79-80
+    if (t.kind == HRT_TEX_IMAGE) {  // texture.cpp:53-74
+        u = gclamp(u, 0.0f, 1.0f);
+        v = 1.0f - gclamp(v, 0.0f, 1.0f);
+        int i = static_cast<int>(u * t.width);
+        int j = static_cast<int>(v * t.height);
+        if (i >= t.width) i = t.width - 1;
+        if (j >= t.height) j = t.height - 1;
+        const float colourScale = 1.0f / 255.0f;
+        const uint8_t* px = sc.texels_u8 + t.offset + (size_t)j * (3 * t.width) + (size_t)i * 3;
+        return vec3(colourScale * px[0], colourScale * px[1], colourScale * px[2]);
+    }
+    // HRT_TEX_ENV: texture.cpp:76-97
+    u = gclamp(u, 0.0f, 1.0f);
+    v = gclamp(v, 0.0f, 1.0f);
+    int i = static_cast<int>((u * (t.width - 1)) + 0.5f);
+    int j = static_cast<int>((v * (t.height - 1)) + 0.5f);
+    const float* px = sc.texels_f32 + t.offset + ((size_t)j * t.width + i) * t.channels;
+    return vec3(px[0], px[1], px[2]);
+}
+__device__ inline vec3 tex_value(const DScene& sc, int tex, float u, float v, vec3 p) {
+    // CheckeredTexture (texture.cpp:17-28) may nest; bounded walk instead of recursion
+    for (int depth = 0; depth < 4; ++depth) {
+        const hrt_texture& t = sc.texs[tex];
+        if (t.kind != HRT_TEX_CHECKER) return tex_leaf(sc, t, u, v);
+        float sines = gsin(10 * p.x) * gsin(10 * p.y) * gsin(10 * p.z);
+        tex = (sines < 0) ? t.odd : t.even;
+    }
+    return vec3(0, 1, 1);
+}
+__device__ inline vec3 matvec3_value(const DScene& sc, const hrt_matvec3& m, float u, float v, vec3 p) {
+    if (m.tex < 0) return vec3(m.c[0], m.c[1], m.c[2]);
+    return tex_value(sc, m.tex, u, v, p);
+}
+__device__ inline float matscalar_value(const DScene& sc, const hrt_matscalar& m, float u, float v, vec3 p) {
+    if (m.tex < 0) return m.c;
+    return length(tex_value(sc, m.tex, u, v, p));
+}
+
+// ------------------------------------------------------------------ Material::emitted / scatter (material.h, material.cpp)
+// Returns false when the path ends (DiffuseLight, absorbed Metal).
+__device__ inline bool material_scatter(const DScene& sc, const DRec& rec, vec3 rin_d, const rng_ctx& ctx, vec3& emitted,
+                                        vec3& attenuation, vec3& so, vec3& sd) {
+    const hrt_material& m = sc.mats[rec.mat];
+    int kind = m.kind;
+    emitted = vec3(0.0f);
+    if (kind == HRT_MAT_DIFFUSE_LIGHT) {  // material.h:96-104
+        emitted = matvec3_value(sc, m.albedo, rec.u, rec.v, rec.p) * matscalar_value(sc, m.s0, rec.u, rec.v, rec.p);
+        return false;
+    }
+    so = rec.p;
+    if (kind == HRT_MAT_ISOTROPIC) {  // material.h:79-85
+        sd = ball_rand(ctx);
+        attenuation = matvec3_value(sc, m.albedo, rec.u, rec.v, rec.p);
+        return true;
+    }
+    const u32x4 dr = rng_draw(ctx, RNG_SCATTER, 0);
+    const vec3 sph = spherical_rand(dr.x, dr.y);
+    if (kind == HRT_MAT_PBR) {  // material.cpp:18-28
+        bool metal = length(tex_value(sc, m.mix_tex, rec.u, rec.v, rec.p)) > 0.5f;
+        kind = metal ? HRT_MAT_METAL : HRT_MAT_LAMBERTIAN;
+    }
+    if (kind == HRT_MAT_LAMBERTIAN || kind == HRT_MAT_UVTEST) {  // material.h:137-153, 116-129
+        vec3 scatterDirection = rec.normal + sph;
+        if (near_zero(scatterDirection)) scatterDirection = rec.normal;
+        sd = scatterDirection;
+        attenuation = (kind == HRT_MAT_UVTEST) ? rec.normal : matvec3_value(sc, m.albedo, rec.u, rec.v, rec.p);
+        return true;
+    }
+    if (kind == HRT_MAT_METAL) {  // material.h:166-177
+        vec3 nn = normalize(rec.normal);
+        vec3 reflected = reflect(normalize(rin_d), nn);
+        float roughness = fabsf(matscalar_value(sc, m.s0, rec.u, rec.v, rec.p));
+        roughness = roughness < 1 ? roughness : 1;
+        sd = reflected + roughness * sph + vec3(1.1920928955078125e-7f);
+        attenuation = matvec3_value(sc, m.albedo, rec.u, rec.v, rec.p);
+        return dot(sd, nn) > 0;
+    }
+    // HRT_MAT_DIELECTRIC: material.h:204-229, 236-241
+    attenuation = vec3(1, 1, 1);
+    float irv = matscalar_value(sc, m.s0, rec.u, rec.v, rec.p);
+    float refractionRatio = rec.frontFace ? (1.0f / irv) : irv;
+    vec3 unitDirection = normalize(rin_d);
+    double cosTheta = gmin(dot(-unitDirection, rec.normal), 1.0f);
+    double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
+    bool cannot_refract = refractionRatio * sinTheta > 1.0;
+    double r0 = (1 - refractionRatio) / (1 + refractionRatio);
+    r0 = r0 * r0;
+    double ref = r0 + (1 - r0) * pow5(1 - cosTheta);
+    vec3 direction;
+    if (cannot_refract || ref > u01d(dr.z, dr.w)) direction = reflect(unitDirection, rec.normal);
+    else direction = refract(unitDirection, rec.normal, refractionRatio);
+    sd = direction + matscalar_value(sc, m.s1, rec.u, rec.v, rec.p) * sph;
+    return true;
+}
+
+// main.cpp:47-58
+__device__ inline vec3 background_value(const DScene& sc, vec3 d) {
+    const float pi = 3.14159265358979323846264338327950288f;
+    vec3 nD = normalize(d);
+    float phi = gatan2(nD.z, nD.x);
+    float theta = gacos(nD.y);
+    float u = phi / (2 * pi) + 0.5f;
+    float v = theta / pi;
+    return tex_value(sc, sc.background_tex, u, v, vec3(0.0f));
+}
+
+// film.cpp:32-52 + 25-30
+__device__ inline void film_resolve(vec3 c, uint8_t* out) {
+    if (c.x != c.x) c.x = 0.0f;
+    if (c.y != c.y) c.y = 0.0f;
+    if (c.z != c.z) c.z = 0.0f;
+    const float a = 2.51f, b = 0.03f, cc = 2.43f, dd = 0.59f, e = 0.14f;
+    vec3 num = c * (a * c + b);
+    vec3 den = c * (cc * c + dd) + e;
+    vec3 q = num / den;
+    q = vec3(gclamp(q.x, 0.0f, 1.0f), gclamp(q.y, 0.0f, 1.0f), gclamp(q.z, 0.0f, 1.0f));
+    q = vec3(sqrtf(q.x), sqrtf(q.y), sqrtf(q.z));
+    out[0] = static_cast<uint8_t>(256 * gclamp(q.x, 0.0f, 0.9999f));
+    out[1] = static_cast<uint8_t>(256 * gclamp(q.y, 0.0f, 0.9999f));
+    out[2] = static_cast<uint8_t>(256 * gclamp(q.z, 0.0f, 0.9999f));
+}
+
+}  // namespace hrt

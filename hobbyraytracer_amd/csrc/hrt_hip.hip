@@ -1,0 +1,709 @@
+// hrt_hip.hip — HIP kernels for gfx950 (MI355X) and the C ABI of include/hrt.h.
+//
+// Kernels:
+//   k_pathtrace<STATS>  render() + rayColour() of main.cpp:38-140 as a
+//                       persistent-lanes kernel: every lane owns one pixel at a
+//                       time and walks its samples in order (so the fp32 sum
+//                       per pixel has the reference's order, main.cpp:118-126);
+//                       when a pixel is finished the lane pulls the next one
+//                       from a global counter (one aggregated atomic per wave,
+//                       64-bit ballot), so lanes stay busy whatever the path
+//                       lengths of their neighbours are.
+//   k_resolve           Film::tonemap + Film::writeColour (film.cpp:25-52).
+//   k_closest_hit       world->hit() for test rays (parity tests).
+//   k_math_probe        the shared math kernels, for CPU==GPU bit tests.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "hrt_device.h"
+
+using namespace hrt;
+
+// ===================================================================== kernels
+namespace {
+
+struct RenderMap {
+    int32_t mode;            // 0 = rect tile, 1 = interleaved row blocks
+    int32_t x0, y0;          // rect origin
+    int32_t rw, rh;          // local region size
+    int32_t R, rank, G;      // stripes
+    int32_t tiles_x;         // ceil(rw / 8)
+    int32_t total_items;     // tiles_x * ceil(rh / 8) * 64
+};
+
+struct DeviceCounters {      // 64-bit accumulators in device memory
+    unsigned long long rays, samples, box_tests, tri_tests, mesh_hits, env_lookups;
+};
+
+__device__ inline unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(HRT_BLOCK) void k_pathtrace(DScene sc, hrt_camera cam, hrt_params pr, RenderMap map,
+                                                         float* __restrict__ out, DeviceCounters* counters,
+                                                         unsigned* work_counter) {
+    __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+
+    const vec3 c_origin(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const vec3 c_llc(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
+    const vec3 c_hor(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    const vec3 c_ver(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    const float INF = __builtin_huge_valf();
+
+    // lane state
+    int out_index = -1;          // local pixel (row-major in the region); -1 = lane holds no pixel
+    int px = 0, py = 0;          // absolute pixel
+    uint32_t pidx = 0;
+    int s = 0;
+    bool new_sample = false;
+    bool exhausted = false;
+    vec3 sum(0.0f), o(0.0f), d(0.0f), atten(1.0f), result(0.0f);
+    int bounce = 0;
+    unsigned n_rays = 0, n_samples = 0, n_mesh = 0, n_env = 0;
+    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+
+    for (;;) {
+        // ---- refill: lanes without a pixel draw work items (one atomic per wave)
+        const bool need = (out_index < 0) && !exhausted;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask) {
+            const int leader = __ffsll((long long)need_mask) - 1;
+            unsigned base = 0;
+            if ((int)lane == leader) base = atomicAdd(work_counter, (unsigned)__popcll(need_mask));
+            base = __shfl(base, leader, 64);
+            if (need) {
+                const unsigned item = base + (unsigned)__popcll(need_mask & ((1ull << lane) - 1ull));
+                if (item >= (unsigned)map.total_items) {
+                    exhausted = true;
+                } else {
+                    const int tile = (int)(item >> 6), within = (int)(item & 63u);
+                    const int tx = tile % map.tiles_x, ty = tile / map.tiles_x;
+                    const int lx = tx * 8 + (within & 7), ly = ty * 8 + (within >> 3);
+                    if (lx < map.rw && ly < map.rh) {
+                        if (map.mode == 0) { px = map.x0 + lx; py = map.y0 + ly; }
+                        else { const int b = ly / map.R; px = lx; py = (b * map.G + map.rank) * map.R + (ly - b * map.R); }
+                        out_index = ly * map.rw + lx;
+                        pidx = (uint32_t)(py * pr.width + px);
+                        s = 0; new_sample = true; sum = vec3(0.0f);
+                    }
+                }
+            }
+        }
+        if (__ballot((out_index >= 0) || !exhausted) == 0ull) break;
+
+        if (out_index >= 0) {
+            rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi; ctx.pixel = pidx; ctx.sample = (uint32_t)s;
+            if (new_sample) {
+                // main.cpp:115-123 + Camera::getRay (camera.h:29-39)
+                ctx.bounce = 0;
+                const u32x4 j = rng_draw(ctx, RNG_JITTER, 0);
+                const int x = px;
+                const int y = pr.height - py;
+                const float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (pr.width - 1);
+                const float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (pr.height - 1);
+                o = c_origin;
+                d = c_llc + u * c_hor + v * c_ver - c_origin;
+                atten = vec3(1.0f); result = vec3(0.0f); bounce = 0; new_sample = false;
+                n_samples++;
+            }
+            // ---- one path segment: the body of the loop at main.cpp:43-76
+            ctx.bounce = (uint32_t)bounce;
+            n_rays++;
+            const WorldHit wh = world_hit<STATS>(sc, o, d, pr.t_min, INF, pr.quirks, ctx, stack, cnt);
+            bool ended;
+            if (wh.prim < 0) {
+                if (STATS && sc.texs[sc.background_tex].kind == HRT_TEX_ENV) n_env++;
+                result += atten * background_value(sc, d);
+                ended = true;
+            } else {
+                if (STATS && sc.prims[wh.prim].kind == HRT_PRIM_MESH) n_mesh++;
+                DRec rec;
+                world_rec(sc, wh, o, d, pr.quirks, rec);
+                vec3 emitted, attenuation, so, sd;
+                const bool b = material_scatter(sc, rec, d, ctx, emitted, attenuation, so, sd);
+                result += atten * emitted;
+                if (!b) {
+                    ended = true;
+                } else {
+                    atten *= attenuation;
+                    o = so; d = sd;
+                    bounce++;
+                    ended = bounce >= pr.max_depth;
+                }
+            }
+            if (ended) {
+                sum += result;
+                s++;
+                new_sample = true;
+                if (s >= pr.samples) {
+                    const vec3 mean = sum / static_cast<float>(pr.samples);  // main.cpp:126
+                    float* op = out + 3ull * (unsigned)out_index;
+                    op[0] = mean.x; op[1] = mean.y; op[2] = mean.z;
+                    out_index = -1;
+                }
+            }
+        }
+    }
+
+    // ---- counters: one 64-bit atomic per wave per counter
+    const unsigned r = wave_sum(n_rays), sm = wave_sum(n_samples);
+    unsigned bt = 0, tt = 0, mh = 0, ev = 0;
+    if (STATS) { bt = wave_sum(cnt.box_tests); tt = wave_sum(cnt.tri_tests); mh = wave_sum(n_mesh); ev = wave_sum(n_env); }
+    if (lane == 0) {
+        atomicAdd(&counters->rays, (unsigned long long)r);
+        atomicAdd(&counters->samples, (unsigned long long)sm);
+        if (STATS) {
+            atomicAdd(&counters->box_tests, (unsigned long long)bt);
+            atomicAdd(&counters->tri_tests, (unsigned long long)tt);
+            atomicAdd(&counters->mesh_hits, (unsigned long long)mh);
+            atomicAdd(&counters->env_lookups, (unsigned long long)ev);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ rgb, long long n_pixels, uint8_t* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n_pixels; i += stride) {
+        uint8_t q[3];
+        film_resolve(vec3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]), q);
+        out[3 * i] = q[0]; out[3 * i + 1] = q[1]; out[3 * i + 2] = q[2];
+    }
+}
+
+__global__ __launch_bounds__(HRT_BLOCK) void k_closest_hit(DScene sc, hrt_params pr, long long n, const float* __restrict__ ro,
+                                                           const float* __restrict__ rd, float t_min, float t_max,
+                                                           uint32_t pixel0, hrt_hit* __restrict__ out) {
+    __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const vec3 o(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
+    const vec3 d(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi; ctx.pixel = pixel0 + (uint32_t)i; ctx.sample = 0; ctx.bounce = 0;
+    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+    const WorldHit wh = world_hit<false>(sc, o, d, t_min, t_max, pr.quirks, ctx, stack, cnt);
+    hrt_hit h;
+    memset(&h, 0, sizeof(h));
+    h.prim = wh.prim; h.tri = -1;
+    if (wh.prim >= 0) {
+        DRec rec;
+        world_rec(sc, wh, o, d, pr.quirks, rec);
+        h.t = rec.t;
+        h.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? wh.sub : -1;
+        h.front_face = rec.frontFace ? 1 : 0;
+        h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
+        h.normal[0] = rec.normal.x; h.normal[1] = rec.normal.y; h.normal[2] = rec.normal.z;
+        h.u = rec.u; h.v = rec.v;
+    }
+    out[i] = h;
+}
+
+__global__ void k_math_probe(int op, long long n, const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (op) {
+        case 0: out[i] = gsin(in[i]); break;
+        case 1: out[i] = gcos(in[i]); break;
+        case 2: out[i] = gacos(in[i]); break;
+        case 3: out[i] = gatan2(in2[i], in[i]); break;
+        case 4: out[i] = glog(in[i]); break;
+        case 5: {
+            u32x4 r = philox4x32_10(f2u(in[4 * i]), f2u(in[4 * i + 1]), f2u(in[4 * i + 2]), f2u(in[4 * i + 3]), f2u(in2[2 * i]),
+                                    f2u(in2[2 * i + 1]));
+            out[4 * i] = u2f(r.x); out[4 * i + 1] = u2f(r.y); out[4 * i + 2] = u2f(r.z); out[4 * i + 3] = u2f(r.w);
+            break;
+        }
+        default: out[i] = 0.0f;
+    }
+}
+
+}  // namespace
+
+// ===================================================================== host side of the ABI
+namespace {
+thread_local std::string g_err;
+
+hrt_status fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return HRT_ERR_HIP;
+}
+hrt_status fail(hrt_status s, const std::string& msg) { g_err = msg; return s; }
+
+#define HIPCHK(expr)                                         \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return fail_hip(_e, #expr);    \
+    } while (0)
+
+template <typename T>
+hrt_status upload(T** dptr, const void* src, size_t bytes) {
+    *dptr = nullptr;
+    size_t alloc = bytes ? bytes : 16;
+    hipError_t e = hipMalloc((void**)dptr, alloc);
+    if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP; }
+    if (bytes) HIPCHK(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+    return HRT_OK;
+}
+
+bool finite3(const float* p) { return p[0] == p[0] && p[1] == p[1] && p[2] == p[2]; }
+}  // namespace
+
+struct hrt_scene {
+    int device = 0;
+    int n_cus = 256;
+    DScene ds{};
+    std::vector<void*> allocs;
+    DeviceCounters* d_counters = nullptr;
+    unsigned* d_work = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // events of launches not yet folded into kernel_ms
+    struct Pending { hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    double kernel_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+namespace {
+
+// Structural validation: every index the kernels follow must be in range, the
+// BVH must be a tree no deeper than the LDS stack (hrt_device.h), so that a
+// malformed scene is refused here instead of faulting the GPU.
+hrt_status validate(const hrt_flat_scene* f) {
+    if (!f) return fail(HRT_ERR_INVALID, "flat scene is NULL");
+    if (f->n_prims && !f->prims) return fail(HRT_ERR_INVALID, "prims is NULL");
+    if (f->n_textures == 0 || !f->textures) return fail(HRT_ERR_INVALID, "scene needs at least the background texture");
+    if (f->background_tex < 0 || (uint32_t)f->background_tex >= f->n_textures) return fail(HRT_ERR_INVALID, "background_tex out of range");
+    for (uint32_t i = 0; i < f->n_textures; ++i) {
+        const hrt_texture& t = f->textures[i];
+        if (t.kind < HRT_TEX_SOLID || t.kind > HRT_TEX_ENV) return fail(HRT_ERR_INVALID, "texture kind out of range");
+        if (t.kind == HRT_TEX_CHECKER) {
+            if (t.even < 0 || (uint32_t)t.even >= f->n_textures || t.odd < 0 || (uint32_t)t.odd >= f->n_textures)
+                return fail(HRT_ERR_INVALID, "checker child out of range");
+        }
+        if (t.kind == HRT_TEX_IMAGE && t.width > 0) {
+            if (t.height <= 0) return fail(HRT_ERR_INVALID, "image texture height");
+            if (t.offset + (uint64_t)t.width * t.height * 3 > f->n_texels_u8) return fail(HRT_ERR_INVALID, "image texels out of range");
+        }
+        if (t.kind == HRT_TEX_ENV && t.width > 0) {
+            if (t.height <= 0 || t.channels < 3) return fail(HRT_ERR_INVALID, "environment map needs >= 3 channels");
+            if (t.offset + (uint64_t)t.width * t.height * t.channels > f->n_texels_f32) return fail(HRT_ERR_INVALID, "env texels out of range");
+        }
+    }
+    auto tex_ok = [&](int32_t t) { return t < 0 || (uint32_t)t < f->n_textures; };
+    for (uint32_t i = 0; i < f->n_materials; ++i) {
+        const hrt_material& m = f->materials[i];
+        if (m.kind < HRT_MAT_LAMBERTIAN || m.kind > HRT_MAT_UVTEST) return fail(HRT_ERR_INVALID, "material kind out of range");
+        if (!tex_ok(m.albedo.tex) || !tex_ok(m.s0.tex) || !tex_ok(m.s1.tex)) return fail(HRT_ERR_INVALID, "material texture out of range");
+        if (m.kind == HRT_MAT_PBR && (m.mix_tex < 0 || (uint32_t)m.mix_tex >= f->n_textures)) return fail(HRT_ERR_INVALID, "pbr mix texture out of range");
+    }
+    for (uint32_t i = 0; i < f->n_meshes; ++i) {
+        const hrt_mesh& m = f->meshes[i];
+        if ((uint64_t)m.tri_first + m.tri_count > f->n_tris) return fail(HRT_ERR_INVALID, "mesh triangle range out of bounds");
+        if ((uint64_t)m.node_first + m.node_count > f->n_nodes) return fail(HRT_ERR_INVALID, "mesh node range out of bounds");
+        if (m.tri_count >= (1u << 28)) return fail(HRT_ERR_UNSUPPORTED, "mesh too large for the leaf encoding");
+        if (m.tri_count > 0 && m.node_count == 0) return fail(HRT_ERR_INVALID, "mesh has triangles but no BVH nodes");
+        // walk the tree: indices in range, every node reached once, depth bounded, every triangle covered
+        if (m.node_count) {
+            std::vector<uint8_t> seen(m.node_count, 0);
+            std::vector<uint8_t> tri_seen(m.tri_count, 0);
+            std::vector<std::pair<int32_t, int>> st;
+            st.push_back({0, 1});
+            while (!st.empty()) {
+                auto [ni, depth] = st.back(); st.pop_back();
+                if (ni < 0 || (uint32_t)ni >= m.node_count) return fail(HRT_ERR_INVALID, "BVH child index out of range");
+                if (seen[ni]) return fail(HRT_ERR_INVALID, "BVH is not a tree (node reached twice)");
+                seen[ni] = 1;
+                if (depth > HRT_STACK_DEPTH) return fail(HRT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+                const hrt_bvh_node& n = f->nodes[m.node_first + ni];
+                const int32_t ch[2] = {n.child0, n.child1};
+                const bool empty[2] = {n.c0_min_x > n.c0_max_x, n.c1_min_x > n.c1_max_x};
+                for (int c = 0; c < 2; ++c) {
+                    if (empty[c]) continue;
+                    if (ch[c] >= 0) st.push_back({ch[c], depth + 1});
+                    else {
+                        uint32_t enc = (uint32_t)~ch[c];
+                        uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+                        if ((uint64_t)first + count > m.tri_count) return fail(HRT_ERR_INVALID, "BVH leaf triangle range out of bounds");
+                        for (uint32_t k = 0; k < count; ++k) tri_seen[first + k] = 1;
+                    }
+                }
+            }
+            for (uint32_t k = 0; k < m.tri_count; ++k)
+                if (!tri_seen[k]) return fail(HRT_ERR_INVALID, "BVH does not cover every triangle");
+        }
+    }
+    for (uint32_t i = 0; i < f->n_prims; ++i) {
+        const hrt_prim& p = f->prims[i];
+        if (p.kind < HRT_PRIM_SPHERE || p.kind > HRT_PRIM_MEDIUM) return fail(HRT_ERR_INVALID, "prim kind out of range");
+        if (p.material < 0 || (uint32_t)p.material >= f->n_materials) return fail(HRT_ERR_INVALID, "prim material out of range");
+        if (p.kind == HRT_PRIM_MESH && (p.mesh < 0 || (uint32_t)p.mesh >= f->n_meshes)) return fail(HRT_ERR_INVALID, "prim mesh out of range");
+        if (p.kind == HRT_PRIM_MEDIUM) {
+            if (p.boundary_kind != HRT_PRIM_SPHERE && p.boundary_kind != HRT_PRIM_BOX)
+                return fail(HRT_ERR_UNSUPPORTED, "constant medium boundary must be a sphere or a box");
+            if (!(p.density > 0.0f)) return fail(HRT_ERR_INVALID, "constant medium density must be > 0");
+        }
+        if (p.n_xforms < 0 || p.n_xforms > HRT_MAX_XFORMS) return fail(HRT_ERR_INVALID, "too many instance wrappers");
+        for (int k = 0; k < p.n_xforms; ++k)
+            if (p.xf[k].kind < HRT_XF_TRANSLATE || p.xf[k].kind > HRT_XF_ROTATE_Y) return fail(HRT_ERR_INVALID, "wrapper kind out of range");
+    }
+    if (f->n_tris && (!f->tri_pos || !f->tri_nrm || !f->tri_uv)) return fail(HRT_ERR_INVALID, "triangle arrays missing");
+    return HRT_OK;
+}
+
+hrt_status check_params(const hrt_params* p) {
+    if (!p) return fail(HRT_ERR_INVALID, "params is NULL");
+    if (p->width < 2 || p->height < 2) return fail(HRT_ERR_INVALID, "film must be at least 2x2 (main.cpp:120-121 divides by W-1, H-1)");
+    if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HRT_ERR_UNSUPPORTED, "film larger than 2^30 pixels");
+    if (p->samples < 1) return fail(HRT_ERR_INVALID, "samples must be >= 1");
+    if (p->max_depth < 1) return fail(HRT_ERR_INVALID, "max_depth must be >= 1");
+    return HRT_OK;
+}
+
+hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
+                            hipStream_t stream) {
+    if (map.total_items <= 0) return HRT_OK;
+    HIPCHK(hipMemsetAsync(sc->d_work, 0, sizeof(unsigned), stream));
+    int blocks = (map.total_items + HRT_BLOCK - 1) / HRT_BLOCK;
+    const int cap = sc->n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, stream));
+    if (pr->flags & HRT_FLAG_STATS)
+        hipLaunchKernelGGL(k_pathtrace<true>, dim3(blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *cam, *pr, map, d_out, sc->d_counters, sc->d_work);
+    else
+        hipLaunchKernelGGL(k_pathtrace<false>, dim3(blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *cam, *pr, map, d_out, sc->d_counters, sc->d_work);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b, stream));
+    sc->pending.push_back({a, b});
+    sc->launches++;
+    return HRT_OK;
+}
+
+hrt_status fold_pending(hrt_scene* sc) {
+    for (auto& p : sc->pending) {
+        HIPCHK(hipEventSynchronize(p.b));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+        sc->kernel_ms += ms;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    sc->pending.clear();
+    return HRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hrt_status_str(hrt_status s) {
+    switch (s) {
+        case HRT_OK: return "ok";
+        case HRT_ERR_INVALID: return "invalid argument";
+        case HRT_ERR_HIP: return "HIP runtime error";
+        case HRT_ERR_NO_DEVICE: return "no GPU device";
+        case HRT_ERR_OOM: return "out of device memory";
+        case HRT_ERR_IO: return "I/O error";
+        case HRT_ERR_PARSE: return "parse error";
+        case HRT_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown";
+}
+const char* hrt_last_error(void) { return g_err.c_str(); }
+const char* hrt_version(void) { return "hrt-mi355x 0.1 (gfx950)"; }
+
+hrt_status hrt_device_count(int* n) {
+    if (!n) return fail(HRT_ERR_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail_hip(e, "hipGetDeviceCount"); }
+    *n = c;
+    return HRT_OK;
+}
+
+void hrt_scene_destroy(hrt_scene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    for (auto& p : sc->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (void* p : sc->allocs) (void)hipFree(p);
+    delete sc;
+}
+
+hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out) {
+    if (!out) return fail(HRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    hrt_status st = validate(f);
+    if (st != HRT_OK) return st;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(HRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(HRT_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+
+    hrt_scene* sc = new (std::nothrow) hrt_scene;
+    if (!sc) return fail(HRT_ERR_OOM, "host allocation failed");
+    sc->device = device;
+    sc->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+#define UP(dst, src, bytes)                                              \
+    do {                                                                 \
+        st = upload(&(dst), (src), (bytes));                             \
+        if (st != HRT_OK) { hrt_scene_destroy(sc); return st; }          \
+        sc->allocs.push_back((void*)(dst));                              \
+    } while (0)
+
+    hrt_prim* d_prims; hrt_material* d_mats; hrt_texture* d_texs; hrt_mesh* d_meshes;
+    UP(d_prims, f->prims, sizeof(hrt_prim) * f->n_prims);
+    UP(d_mats, f->materials, sizeof(hrt_material) * f->n_materials);
+    UP(d_texs, f->textures, sizeof(hrt_texture) * f->n_textures);
+    UP(d_meshes, f->meshes, sizeof(hrt_mesh) * f->n_meshes);
+    float4* d_nodes;
+    UP(d_nodes, f->nodes, sizeof(hrt_bvh_node) * f->n_nodes);
+
+    // repack triangles into 16-byte aligned records
+    const size_t nt = (size_t)f->n_tris;
+    std::vector<float> pos(nt * 12), attr(nt * 16), box(nt * 8);
+    for (size_t i = 0; i < nt; ++i) {
+        const float* p = f->tri_pos + 9 * i; const float* n = f->tri_nrm + 9 * i; const float* uv = f->tri_uv + 6 * i;
+        for (int k = 0; k < 3; ++k) { pos[12 * i + 4 * k] = p[3 * k]; pos[12 * i + 4 * k + 1] = p[3 * k + 1]; pos[12 * i + 4 * k + 2] = p[3 * k + 2]; pos[12 * i + 4 * k + 3] = 0.0f; }
+        float* a = &attr[16 * i];
+        a[0] = n[0]; a[1] = n[1]; a[2] = n[2]; a[3] = uv[0];
+        a[4] = n[3]; a[5] = n[4]; a[6] = n[5]; a[7] = uv[1];
+        a[8] = n[6]; a[9] = n[7]; a[10] = n[8]; a[11] = uv[2];
+        a[12] = uv[3]; a[13] = uv[4]; a[14] = uv[5]; a[15] = 0.0f;
+        float* b = &box[8 * i];
+        if (f->tri_box) {
+            const float* s = f->tri_box + 6 * i;
+            b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[3] = 0.0f; b[4] = s[3]; b[5] = s[4]; b[6] = s[5]; b[7] = 0.0f;
+        } else {  // triangle.cpp:133-151
+            for (int c = 0; c < 3; ++c) {
+                float mn = gmin(gmin(p[c], p[3 + c]), p[6 + c]);
+                float mx = gmax(gmax(p[c], p[3 + c]), p[6 + c]);
+                b[c] = mn - 0.0001f; b[4 + c] = mx + 0.0001f;
+            }
+            b[3] = b[7] = 0.0f;
+        }
+    }
+    float4 *d_pos, *d_attr, *d_box;
+    UP(d_pos, pos.data(), pos.size() * sizeof(float));
+    UP(d_attr, attr.data(), attr.size() * sizeof(float));
+    UP(d_box, box.data(), box.size() * sizeof(float));
+    uint8_t* d_u8; float* d_f32;
+    UP(d_u8, f->texels_u8, (size_t)f->n_texels_u8);
+    UP(d_f32, f->texels_f32, (size_t)f->n_texels_f32 * sizeof(float));
+    DeviceCounters zero{};
+    UP(sc->d_counters, &zero, sizeof(zero));
+    unsigned zw = 0;
+    UP(sc->d_work, &zw, sizeof(zw));
+#undef UP
+
+    sc->ds.prims = d_prims; sc->ds.mats = d_mats; sc->ds.texs = d_texs; sc->ds.meshes = d_meshes;
+    sc->ds.nodes = d_nodes; sc->ds.tri_pos = d_pos; sc->ds.tri_attr = d_attr; sc->ds.tri_box = d_box;
+    sc->ds.texels_u8 = d_u8; sc->ds.texels_f32 = d_f32;
+    sc->ds.n_prims = (int32_t)f->n_prims;
+    sc->ds.background_tex = f->background_tex;
+    *out = sc;
+    return HRT_OK;
+}
+
+int32_t hrt_stripe_rows(int32_t height, int32_t R, int32_t rank, int32_t G) {
+    if (height <= 0 || R <= 0 || G <= 0 || rank < 0 || rank >= G) return 0;
+    const int32_t n_blocks = (height + R - 1) / R;
+    int32_t rows = 0;
+    for (int32_t b = rank; b < n_blocks; b += G) {
+        const int32_t r0 = b * R;
+        rows += (r0 + R <= height) ? R : (height - r0);
+    }
+    return rows;
+}
+int32_t hrt_stripe_row_index(int32_t height, int32_t R, int32_t rank, int32_t G, int32_t local) {
+    if (local < 0 || local >= hrt_stripe_rows(height, R, rank, G)) return -1;
+    const int32_t b = local / R;
+    return (b * G + rank) * R + (local - b * R);
+}
+
+hrt_status hrt_render_stripes_device(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank,
+                                     int32_t G, float* d_out, void* stream) {
+    if (!sc || !cam || !d_out) return fail(HRT_ERR_INVALID, "NULL argument");
+    hrt_status st = check_params(pr);
+    if (st != HRT_OK) return st;
+    if (R <= 0 || G <= 0 || rank < 0 || rank >= G) return fail(HRT_ERR_INVALID, "bad stripe partition");
+    HIPCHK(hipSetDevice(sc->device));
+    RenderMap map{};
+    map.mode = 1; map.R = R; map.rank = rank; map.G = G;
+    map.rw = pr->width; map.rh = hrt_stripe_rows(pr->height, R, rank, G);
+    map.tiles_x = (map.rw + 7) / 8;
+    map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
+    return launch_pathtrace(sc, cam, pr, map, d_out, (hipStream_t)stream);
+}
+
+hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
+    if (!sc || !stats) return fail(HRT_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(sc->device));
+    HIPCHK(hipDeviceSynchronize());
+    hrt_status st = fold_pending(sc);
+    if (st != HRT_OK) return st;
+    DeviceCounters c;
+    HIPCHK(hipMemcpy(&c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
+    stats->rays = c.rays; stats->samples = c.samples; stats->box_tests = c.box_tests; stats->tri_tests = c.tri_tests;
+    stats->mesh_hits = c.mesh_hits; stats->env_lookups = c.env_lookups;
+    stats->kernel_ms = sc->kernel_ms; stats->launches = sc->launches;
+    sc->kernel_ms = 0.0; sc->launches = 0;
+    return HRT_OK;
+}
+
+hrt_status hrt_render_tile(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, hrt_rect tile, float* out,
+                           hrt_stats* stats) {
+    if (!sc || !cam || !out) return fail(HRT_ERR_INVALID, "NULL argument");
+    hrt_status st = check_params(pr);
+    if (st != HRT_OK) return st;
+    if (tile.w <= 0 || tile.h <= 0 || tile.x0 < 0 || tile.y0 < 0 || tile.x0 + tile.w > pr->width || tile.y0 + tile.h > pr->height)
+        return fail(HRT_ERR_INVALID, "tile outside the film");
+    HIPCHK(hipSetDevice(sc->device));
+    // discard counters of earlier async launches so `stats` describes this call only
+    hrt_stats prev;
+    st = hrt_scene_stats(sc, &prev);
+    if (st != HRT_OK) return st;
+    const size_t bytes = (size_t)tile.w * tile.h * 3 * sizeof(float);
+    float* d_out = nullptr;
+    hipError_t e = hipMalloc((void**)&d_out, bytes);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    RenderMap map{};
+    map.mode = 0; map.x0 = tile.x0; map.y0 = tile.y0; map.rw = tile.w; map.rh = tile.h; map.R = 1; map.G = 1;
+    map.tiles_x = (map.rw + 7) / 8;
+    map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
+    st = launch_pathtrace(sc, cam, pr, map, d_out, nullptr);
+    if (st == HRT_OK) {
+        e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail_hip(e, "hipMemcpy D2H film tile");
+    }
+    (void)hipFree(d_out);
+    if (st != HRT_OK) return st;
+    hrt_stats now;
+    st = hrt_scene_stats(sc, &now);
+    if (st != HRT_OK) return st;
+    if (stats) *stats = now;
+    return HRT_OK;
+}
+
+hrt_status hrt_render_stripes(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank, int32_t G,
+                              float* out, hrt_stats* stats) {
+    if (!sc || !cam || !out) return fail(HRT_ERR_INVALID, "NULL argument");
+    hrt_status st = check_params(pr);
+    if (st != HRT_OK) return st;
+    HIPCHK(hipSetDevice(sc->device));
+    hrt_stats prev;
+    st = hrt_scene_stats(sc, &prev);
+    if (st != HRT_OK) return st;
+    const int32_t rows = hrt_stripe_rows(pr->height, R, rank, G);
+    if (R <= 0 || G <= 0 || rank < 0 || rank >= G) return fail(HRT_ERR_INVALID, "bad stripe partition");
+    const size_t bytes = (size_t)rows * pr->width * 3 * sizeof(float);
+    float* d_out = nullptr;
+    if (bytes) {
+        hipError_t e = hipMalloc((void**)&d_out, bytes);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        st = hrt_render_stripes_device(sc, cam, pr, R, rank, G, d_out, nullptr);
+        if (st == HRT_OK) {
+            hipError_t e2 = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) st = fail_hip(e2, "hipMemcpy D2H film stripes");
+        }
+        (void)hipFree(d_out);
+        if (st != HRT_OK) return st;
+    }
+    hrt_stats now;
+    st = hrt_scene_stats(sc, &now);
+    if (st != HRT_OK) return st;
+    if (stats) *stats = now;
+    return HRT_OK;
+}
+
+hrt_status hrt_resolve_u8_device(hrt_scene* sc, const float* d_rgb, int64_t n_pixels, uint8_t* d_out, void* stream) {
+    if (!sc || !d_rgb || !d_out || n_pixels < 0) return fail(HRT_ERR_INVALID, "bad argument");
+    if (n_pixels == 0) return HRT_OK;
+    HIPCHK(hipSetDevice(sc->device));
+    int blocks = (int)((n_pixels + 255) / 256);
+    if (blocks > sc->n_cus * 8) blocks = sc->n_cus * 8;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_rgb, (long long)n_pixels, d_out);
+    HIPCHK(hipGetLastError());
+    return HRT_OK;
+}
+
+hrt_status hrt_resolve_u8(hrt_scene* sc, const float* rgb, int64_t n_pixels, uint8_t* out) {
+    if (!sc || !rgb || !out || n_pixels < 0) return fail(HRT_ERR_INVALID, "bad argument");
+    if (n_pixels == 0) return HRT_OK;
+    HIPCHK(hipSetDevice(sc->device));
+    float* d_in = nullptr; uint8_t* d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_in, (size_t)n_pixels * 12));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n_pixels * 3);
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail_hip(e, "hipMalloc"); }
+    hrt_status st = HRT_OK;
+    e = hipMemcpy(d_in, rgb, (size_t)n_pixels * 12, hipMemcpyHostToDevice);
+    if (e != hipSuccess) st = fail_hip(e, "hipMemcpy H2D");
+    if (st == HRT_OK) st = hrt_resolve_u8_device(sc, d_in, n_pixels, d_out, nullptr);
+    if (st == HRT_OK) { e = hipMemcpy(out, d_out, (size_t)n_pixels * 3, hipMemcpyDeviceToHost); if (e != hipSuccess) st = fail_hip(e, "hipMemcpy D2H"); }
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return st;
+}
+
+hrt_status hrt_closest_hit(hrt_scene* sc, const hrt_params* pr, int64_t n, const float* o, const float* d, float t_min,
+                           float t_max, uint32_t pixel0, hrt_hit* out) {
+    if (!sc || !pr || !o || !d || !out || n < 0) return fail(HRT_ERR_INVALID, "bad argument");
+    if (n == 0) return HRT_OK;
+    HIPCHK(hipSetDevice(sc->device));
+    float *d_o = nullptr, *d_d = nullptr; hrt_hit* d_h = nullptr;
+    hrt_status st = HRT_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_o, (size_t)n * 12)) != hipSuccess) st = fail_hip(e, "hipMalloc");
+    if (st == HRT_OK && (e = hipMalloc((void**)&d_d, (size_t)n * 12)) != hipSuccess) st = fail_hip(e, "hipMalloc");
+    if (st == HRT_OK && (e = hipMalloc((void**)&d_h, (size_t)n * sizeof(hrt_hit))) != hipSuccess) st = fail_hip(e, "hipMalloc");
+    if (st == HRT_OK && (e = hipMemcpy(d_o, o, (size_t)n * 12, hipMemcpyHostToDevice)) != hipSuccess) st = fail_hip(e, "hipMemcpy");
+    if (st == HRT_OK && (e = hipMemcpy(d_d, d, (size_t)n * 12, hipMemcpyHostToDevice)) != hipSuccess) st = fail_hip(e, "hipMemcpy");
+    if (st == HRT_OK) {
+        const int blocks = (int)((n + HRT_BLOCK - 1) / HRT_BLOCK);
+        hipLaunchKernelGGL(k_closest_hit, dim3(blocks), dim3(HRT_BLOCK), 0, 0, sc->ds, *pr, (long long)n, d_o, d_d, t_min, t_max, pixel0, d_h);
+        if ((e = hipGetLastError()) != hipSuccess) st = fail_hip(e, "k_closest_hit launch");
+    }
+    if (st == HRT_OK && (e = hipMemcpy(out, d_h, (size_t)n * sizeof(hrt_hit), hipMemcpyDeviceToHost)) != hipSuccess) st = fail_hip(e, "hipMemcpy D2H");
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h);
+    return st;
+}
+
+hrt_status hrt_math_probe(int device, int32_t op, int64_t n, const float* in, const float* in2, float* out) {
+    if (!in || !out || n < 0 || op < 0 || op > 5) return fail(HRT_ERR_INVALID, "bad argument");
+    if ((op == 3 || op == 5) && !in2) return fail(HRT_ERR_INVALID, "in2 required");
+    if (n == 0) return HRT_OK;
+    HIPCHK(hipSetDevice(device));
+    const size_t n_in = (size_t)n * (op == 5 ? 4 : 1), n_in2 = (size_t)n * (op == 5 ? 2 : 1), n_out = (size_t)n * (op == 5 ? 4 : 1);
+    float *d_in = nullptr, *d_in2 = nullptr, *d_out = nullptr;
+    hrt_status st = HRT_OK; hipError_t e;
+    if ((e = hipMalloc((void**)&d_in, n_in * 4)) != hipSuccess) st = fail_hip(e, "hipMalloc");
+    if (st == HRT_OK && (e = hipMalloc((void**)&d_in2, n_in2 * 4)) != hipSuccess) st = fail_hip(e, "hipMalloc");
+    if (st == HRT_OK && (e = hipMalloc((void**)&d_out, n_out * 4)) != hipSuccess) st = fail_hip(e, "hipMalloc");
+    if (st == HRT_OK && (e = hipMemcpy(d_in, in, n_in * 4, hipMemcpyHostToDevice)) != hipSuccess) st = fail_hip(e, "hipMemcpy");
+    if (st == HRT_OK && in2 && (e = hipMemcpy(d_in2, in2, n_in2 * 4, hipMemcpyHostToDevice)) != hipSuccess) st = fail_hip(e, "hipMemcpy");
+    if (st == HRT_OK) {
+        hipLaunchKernelGGL(k_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (long long)n, d_in, d_in2, d_out);
+        if ((e = hipGetLastError()) != hipSuccess) st = fail_hip(e, "k_math_probe launch");
+    }
+    if (st == HRT_OK && (e = hipMemcpy(out, d_out, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) st = fail_hip(e, "hipMemcpy D2H");
+    (void)hipFree(d_in); (void)hipFree(d_in2); (void)hipFree(d_out);
+    return st;
+}
+
+}  // extern "C"

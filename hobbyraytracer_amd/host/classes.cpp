@@ -1,0 +1,345 @@
+// classes.cpp — flatten() of every class of the reference's surface, Camera,
+// Film and the mesh import seam.  See classes.h.
+#include "classes.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "image_io.h"
+
+namespace hrthost {
+
+// ------------------------------------------------------------------ FlatBuilder
+int FlatBuilder::addTexture(const std::shared_ptr<Texture>& t) {
+    if (!t) throw FlattenError(HRT_ERR_INVALID, "null texture");
+    auto it = tex_ids.find(t.get());
+    if (it != tex_ids.end()) return it->second;
+    const int id = (int)textures.size();
+    tex_ids[t.get()] = id;
+    textures.push_back(hrt_texture{});
+    hrt_texture out{};
+    t->flatten(*this, out);  // may append children (checker)
+    textures[id] = out;
+    return id;
+}
+int FlatBuilder::addMaterial(const std::shared_ptr<Material>& m) {
+    if (!m) throw FlattenError(HRT_ERR_INVALID, "null material");
+    auto it = mat_ids.find(m.get());
+    if (it != mat_ids.end()) return it->second;
+    const int id = (int)materials.size();
+    mat_ids[m.get()] = id;
+    materials.push_back(hrt_material{});
+    hrt_material out{};
+    out.albedo.tex = -1; out.s0.tex = -1; out.s1.tex = -1; out.mix_tex = -1;
+    m->flatten(*this, out);
+    materials[id] = out;
+    return id;
+}
+int FlatBuilder::addMesh(const std::vector<float>& pos, const std::vector<float>& nrm, const std::vector<float>& uv,
+                         const std::vector<float>& box, const std::vector<hrt_bvh_node>& nd) {
+    hrt_mesh m{};
+    m.tri_first = (uint32_t)(tri_pos.size() / 9);
+    m.tri_count = (uint32_t)(pos.size() / 9);
+    m.node_first = (uint32_t)nodes.size();
+    m.node_count = (uint32_t)nd.size();
+    tri_pos.insert(tri_pos.end(), pos.begin(), pos.end());
+    tri_nrm.insert(tri_nrm.end(), nrm.begin(), nrm.end());
+    tri_uv.insert(tri_uv.end(), uv.begin(), uv.end());
+    tri_box.insert(tri_box.end(), box.begin(), box.end());
+    nodes.insert(nodes.end(), nd.begin(), nd.end());
+    meshes.push_back(m);
+    return (int)meshes.size() - 1;
+}
+hrt_flat_scene FlatBuilder::flat() const {
+    hrt_flat_scene f{};
+    f.n_prims = (uint32_t)prims.size(); f.prims = prims.data();
+    f.n_materials = (uint32_t)materials.size(); f.materials = materials.data();
+    f.n_textures = (uint32_t)textures.size(); f.textures = textures.data();
+    f.n_meshes = (uint32_t)meshes.size(); f.meshes = meshes.data();
+    f.n_tris = tri_pos.size() / 9;
+    f.tri_pos = tri_pos.data(); f.tri_nrm = tri_nrm.data(); f.tri_uv = tri_uv.data();
+    f.tri_box = tri_box.size() == 6 * f.n_tris && f.n_tris ? tri_box.data() : nullptr;
+    f.n_nodes = nodes.size(); f.nodes = nodes.data();
+    f.n_texels_u8 = texels_u8.size(); f.texels_u8 = texels_u8.data();
+    f.n_texels_f32 = texels_f32.size(); f.texels_f32 = texels_f32.data();
+    f.background_tex = background;
+    return f;
+}
+
+// ------------------------------------------------------------------ textures
+void SolidColourTexture::flatten(FlatBuilder&, hrt_texture& out) const {
+    out.kind = HRT_TEX_SOLID; out.c[0] = c.x; out.c[1] = c.y; out.c[2] = c.z;
+}
+void CheckeredTexture::flatten(FlatBuilder& fb, hrt_texture& out) const {
+    out.kind = HRT_TEX_CHECKER;
+    out.even = fb.addTexture(e);
+    out.odd = fb.addTexture(o);
+}
+ImageTexture::ImageTexture(std::string filename) : width(0), height(0) {  // texture.cpp:30-51
+    std::string err;
+    if (!loadImageRGB8(filename, data, width, height, err)) {
+        std::cout << "ERROR: Could not load image file: " << filename << std::endl;
+        width = height = 0; data.clear();
+    }
+    std::cout << "Loaded image file: " << filename << std::endl;
+}
+void ImageTexture::flatten(FlatBuilder& fb, hrt_texture& out) const {
+    out.kind = HRT_TEX_IMAGE; out.width = width; out.height = height; out.channels = 3;
+    out.offset = data.empty() ? 0 : fb.addTexelsU8(data);
+    if (data.empty()) out.width = out.height = 0;
+}
+EnvironmentMap::EnvironmentMap(std::string path) : width(0), height(0), channels(0) {  // texture.cpp:99-115
+    std::string err;
+    if (!loadImageF32(path, data, width, height, channels, err)) {
+        std::cout << "ERROR: Could not environment map file: " << path << std::endl;
+        width = height = channels = 0; data.clear();
+        return;
+    }
+    std::cout << "Loaded environment map: " << path << std::endl;
+}
+void EnvironmentMap::flatten(FlatBuilder& fb, hrt_texture& out) const {
+    out.kind = HRT_TEX_ENV; out.width = width; out.height = height; out.channels = channels;
+    out.offset = data.empty() ? 0 : fb.addTexelsF32(data);
+    if (data.empty()) out.width = out.height = 0;
+}
+
+// ------------------------------------------------------------------ materials
+hrt_matvec3 MatVec3::flatten(FlatBuilder& fb) const {
+    hrt_matvec3 m{}; m.tex = tex ? fb.addTexture(tex) : -1; m.c[0] = c.x; m.c[1] = c.y; m.c[2] = c.z; return m;
+}
+hrt_matscalar MatScalar::flatten(FlatBuilder& fb) const {
+    hrt_matscalar m{}; m.tex = tex ? fb.addTexture(tex) : -1; m.c = c; return m;
+}
+void Isotropic::flatten(FlatBuilder& fb, hrt_material& out) const { out.kind = HRT_MAT_ISOTROPIC; out.albedo.tex = fb.addTexture(albedo); }
+void DiffuseLight::flatten(FlatBuilder& fb, hrt_material& out) const { out.kind = HRT_MAT_DIFFUSE_LIGHT; out.albedo = emit.flatten(fb); out.s0 = s.flatten(fb); }
+void UVTest::flatten(FlatBuilder&, hrt_material& out) const { out.kind = HRT_MAT_UVTEST; }
+void Lambertian::flatten(FlatBuilder& fb, hrt_material& out) const { out.kind = HRT_MAT_LAMBERTIAN; out.albedo = albedo.flatten(fb); }
+void Metal::flatten(FlatBuilder& fb, hrt_material& out) const { out.kind = HRT_MAT_METAL; out.albedo = albedo.flatten(fb); out.s0 = r.flatten(fb); }
+void Dielectric::flatten(FlatBuilder& fb, hrt_material& out) const { out.kind = HRT_MAT_DIELECTRIC; out.s0 = ir.flatten(fb); out.s1 = r.flatten(fb); }
+void PBR::flatten(FlatBuilder& fb, hrt_material& out) const {
+    out.kind = HRT_MAT_PBR; out.albedo = alb.flatten(fb); out.s0.tex = -1; out.s0.c = rough; out.mix_tex = fb.addTexture(mix);
+}
+
+// ------------------------------------------------------------------ hittables
+namespace {
+hrt_prim basePrim(FlatBuilder& fb, int kind, const std::shared_ptr<Material>& m) {
+    hrt_prim p{};
+    p.kind = kind; p.material = fb.addMaterial(m); p.mesh = -1; p.boundary_kind = -1; p.density = 0.0f;
+    if (fb.chain.size() > HRT_MAX_XFORMS) throw FlattenError(HRT_ERR_UNSUPPORTED, "more than HRT_MAX_XFORMS nested instance wrappers");
+    p.n_xforms = (int32_t)fb.chain.size();
+    for (size_t k = 0; k < fb.chain.size(); ++k) p.xf[k] = fb.chain[k];
+    return p;
+}
+struct ChainPush {
+    FlatBuilder& fb;
+    ChainPush(FlatBuilder& f, const hrt_xform& x) : fb(f) { fb.chain.push_back(x); }
+    ~ChainPush() { fb.chain.pop_back(); }
+};
+}  // namespace
+
+void HittableList::flatten(FlatBuilder& fb) const {
+    // scene.cpp:376-379: the world is a HittableList; nested lists flatten in place
+    // (HittableList::hit is associative over closest-so-far when there is no wrapper in between)
+    if (!fb.chain.empty()) throw FlattenError(HRT_ERR_UNSUPPORTED, "a HittableList inside an instance wrapper is not supported");
+    for (const auto& o : objects) {
+        if (!o) throw FlattenError(HRT_ERR_INVALID, "null object in the world list (unknown object type? scene.cpp:279,356)");
+        o->flatten(fb);
+    }
+}
+void Sphere::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_SPHERE, matPtr); params(p.p); fb.addPrim(p); }
+void YZRect::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_YZ_RECT, mp); p.p[0] = y0; p.p[1] = y1; p.p[2] = z0; p.p[3] = z1; p.p[4] = k; fb.addPrim(p); }
+void XZRect::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_XZ_RECT, mp); p.p[0] = x0; p.p[1] = x1; p.p[2] = z0; p.p[3] = z1; p.p[4] = k; fb.addPrim(p); }
+void XYRect::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_XY_RECT, mp); p.p[0] = x0; p.p[1] = x1; p.p[2] = y0; p.p[3] = y1; p.p[4] = k; fb.addPrim(p); }
+void Box::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_BOX, matPtr); params(p.p); fb.addPrim(p); }
+
+void Translate::flatten(FlatBuilder& fb) const {
+    hrt_xform x{}; x.kind = HRT_XF_TRANSLATE; x.v[0] = offset.x; x.v[1] = offset.y; x.v[2] = offset.z;
+    ChainPush g(fb, x); ptr->flatten(fb);
+}
+void Scale::flatten(FlatBuilder& fb) const {
+    hrt_xform x{}; x.kind = HRT_XF_SCALE; x.v[0] = factor.x; x.v[1] = factor.y; x.v[2] = factor.z;
+    ChainPush g(fb, x); ptr->flatten(fb);
+}
+void RotateQuat::flatten(FlatBuilder& fb) const {
+    hrt_xform x{}; x.kind = HRT_XF_ROTATE_QUAT; x.v[0] = rotation.x; x.v[1] = rotation.y; x.v[2] = rotation.z; x.v[3] = rotation.w;
+    ChainPush g(fb, x); ptr->flatten(fb);
+}
+RotateY::RotateY(std::shared_ptr<Hittable> p, float angle) : ptr(p) {  // rotateY.cpp:4-9
+    float radians = hrt::gradians(angle);
+    sinTheta = hrt::gsin(radians);
+    cosTheta = hrt::gcos(radians);
+}
+void RotateY::flatten(FlatBuilder& fb) const {
+    hrt_xform x{}; x.kind = HRT_XF_ROTATE_Y; x.v[0] = sinTheta; x.v[1] = cosTheta;
+    ChainPush g(fb, x); ptr->flatten(fb);
+}
+void ConstantMedium::flatten(FlatBuilder& fb) const {
+    hrt_prim p = basePrim(fb, HRT_PRIM_MEDIUM, phaseFunction);
+    if (auto s = std::dynamic_pointer_cast<Sphere>(boundary)) { p.boundary_kind = HRT_PRIM_SPHERE; s->params(p.p); }
+    else if (auto b = std::dynamic_pointer_cast<Box>(boundary)) { p.boundary_kind = HRT_PRIM_BOX; b->params(p.p); }
+    else throw FlattenError(HRT_ERR_UNSUPPORTED, "ConstantMedium boundary must be a Sphere or a Box (a mesh boundary never scatters in the reference: SURVEY Q-5)");
+    p.density = density;
+    fb.addPrim(p);
+}
+
+// ------------------------------------------------------------------ Mesh (mesh.cpp:13-51)
+Mesh::Mesh(std::string filepath, std::shared_ptr<Material> m) : matPtr(m) {
+    std::string err;
+    ok = importFile(filepath, soup, err);
+    if (!ok) {
+        std::cerr << "Assimp error: " << err << std::endl;  // message format of mesh.cpp:59
+        soup = TriangleSoup();
+    } else {
+        std::cout << "Loaded mesh: " << filepath << std::endl;
+    }
+    tree = std::make_shared<BVHNode>(soup);
+    std::cout << "Indexed file: " << filepath << std::endl;
+}
+Mesh::Mesh(TriangleSoup s, std::shared_ptr<Material> m) : soup(std::move(s)), matPtr(m), ok(true) {
+    tree = std::make_shared<BVHNode>(soup);
+}
+void Mesh::flatten(FlatBuilder& fb) const {
+    hrt_prim p = basePrim(fb, HRT_PRIM_MESH, matPtr);
+    p.mesh = fb.addMesh(soup.pos, soup.nrm, soup.uv, tree->leafBoxes, tree->nodes);
+    fb.addPrim(p);
+}
+
+// The import seam.  The reference calls Assimp::Importer::ReadFile(path,
+// aiProcess_Triangulate | aiProcess_FlipUVs) (mesh.cpp:56) and un-indexes the
+// result.  Assimp is an empty submodule in the snapshot, so Wavefront OBJ —
+// the only format the sample scenes use — is parsed here with the same
+// observable result: polygons are fan-triangulated, v -> 1 - v (FlipUVs), no
+// normals are generated (missing normals become (0,0,0): mesh.cpp:83-90, Q-9),
+// missing UVs become (0,0) (mesh.cpp:92-99).  Deviation: a multi-object OBJ is
+// read as ONE mesh with correct indices (the reference appends per-aiMesh
+// indices without rebasing them, Q-8, which scrambles such files).
+bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& err) {
+    std::ifstream f(path);
+    if (!f) { err = "Unable to open file \"" + path + "\"."; return false; }
+    std::string lower = path;
+    for (char& c : lower) c = (char)std::tolower((unsigned char)c);
+    if (lower.size() < 4 || lower.compare(lower.size() - 4, 4, ".obj") != 0) { err = "No suitable reader found for the file format of file \"" + path + "\"."; return false; }
+    std::vector<float> v, vt, vn;
+    std::string line;
+    struct Idx { int v, t, n; };
+    std::vector<Idx> face;
+    int lineNo = 0;
+    while (std::getline(f, line)) {
+        ++lineNo;
+        // line continuation
+        while (!line.empty() && (line.back() == '\r')) line.pop_back();
+        while (!line.empty() && line.back() == '\\') {
+            line.pop_back();
+            std::string more;
+            if (!std::getline(f, more)) break;
+            line += " " + more;
+        }
+        const char* s = line.c_str();
+        while (*s == ' ' || *s == '\t') ++s;
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            float x = 0, y = 0, z = 0;
+            if (std::sscanf(s + 2, "%f %f %f", &x, &y, &z) < 3) { err = "OBJ: bad vertex at line " + std::to_string(lineNo); return false; }
+            v.push_back(x); v.push_back(y); v.push_back(z);
+        } else if (s[0] == 'v' && s[1] == 't') {
+            float a = 0, b = 0;
+            int k = std::sscanf(s + 2, "%f %f", &a, &b);
+            if (k < 1) { err = "OBJ: bad texcoord at line " + std::to_string(lineNo); return false; }
+            vt.push_back(a); vt.push_back(b);
+        } else if (s[0] == 'v' && s[1] == 'n') {
+            float x = 0, y = 0, z = 0;
+            if (std::sscanf(s + 2, "%f %f %f", &x, &y, &z) < 3) { err = "OBJ: bad normal at line " + std::to_string(lineNo); return false; }
+            vn.push_back(x); vn.push_back(y); vn.push_back(z);
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            face.clear();
+            const char* p = s + 1;
+            for (;;) {
+                while (*p == ' ' || *p == '\t') ++p;
+                if (!*p) break;
+                Idx ix{0, 0, 0};
+                char* e;
+                ix.v = (int)std::strtol(p, &e, 10);
+                if (e == p) { err = "OBJ: bad face at line " + std::to_string(lineNo); return false; }
+                p = e;
+                if (*p == '/') {
+                    ++p;
+                    if (*p != '/') { ix.t = (int)std::strtol(p, &e, 10); p = e; }
+                    if (*p == '/') { ++p; ix.n = (int)std::strtol(p, &e, 10); p = e; }
+                }
+                auto fix = [](int i, size_t count) { return i < 0 ? (int)count + i : i - 1; };
+                ix.v = fix(ix.v, v.size() / 3);
+                ix.t = ix.t ? fix(ix.t, vt.size() / 2) : -1;
+                ix.n = ix.n ? fix(ix.n, vn.size() / 3) : -1;
+                if (ix.v < 0 || (size_t)ix.v >= v.size() / 3 || (ix.t >= 0 && (size_t)ix.t >= vt.size() / 2) ||
+                    (ix.n >= 0 && (size_t)ix.n >= vn.size() / 3) || ix.t < -1 || ix.n < -1) {
+                    err = "OBJ: index out of range at line " + std::to_string(lineNo); return false;
+                }
+                face.push_back(ix);
+            }
+            if (face.size() < 3) continue;  // points / lines are dropped by Triangulate
+            for (size_t k = 1; k + 1 < face.size(); ++k) {
+                const Idx tri[3] = {face[0], face[k], face[k + 1]};
+                for (const Idx& ix : tri) {
+                    out.pos.push_back(v[3 * ix.v]); out.pos.push_back(v[3 * ix.v + 1]); out.pos.push_back(v[3 * ix.v + 2]);
+                    if (ix.n >= 0) { out.nrm.push_back(vn[3 * ix.n]); out.nrm.push_back(vn[3 * ix.n + 1]); out.nrm.push_back(vn[3 * ix.n + 2]); }
+                    else { out.nrm.push_back(0); out.nrm.push_back(0); out.nrm.push_back(0); }
+                    if (ix.t >= 0) { out.uv.push_back(vt[2 * ix.t]); out.uv.push_back(1.0f - vt[2 * ix.t + 1]); }
+                    else { out.uv.push_back(0); out.uv.push_back(0); }
+                }
+            }
+        }
+    }
+    if (out.pos.empty()) { err = "OBJ: file contains no faces: " + path; return false; }
+    return true;
+}
+
+// ------------------------------------------------------------------ Camera (camera.h:9-27)
+Camera::Camera(vec3 lookFrom, vec3 lookAt, vec3 up, float vfov, float aspectRatio, float aperture, float focusDistance) {
+    float theta = hrt::gradians(vfov);
+    float h = std::tan(theta / 2);  // setup-time only: the resulting constants are shared by oracle and device
+    float viewportHeight = 2.0f * h;
+    float viewportWidth = aspectRatio * viewportHeight;
+    w = hrt::normalize(lookFrom - lookAt);
+    u = hrt::normalize(hrt::cross(up, w));
+    v = hrt::cross(w, u);
+    origin = lookFrom;
+    horizontal = focusDistance * viewportWidth * u;
+    vertical = focusDistance * viewportHeight * v;
+    lowerLeftCorner = origin - horizontal / 2.0f - vertical / 2.0f - focusDistance * w;
+    lensRadius = aperture / 2.0f;
+}
+hrt_camera Camera::flatten() const {
+    hrt_camera c{};
+    c.origin[0] = origin.x; c.origin[1] = origin.y; c.origin[2] = origin.z;
+    c.lower_left[0] = lowerLeftCorner.x; c.lower_left[1] = lowerLeftCorner.y; c.lower_left[2] = lowerLeftCorner.z;
+    c.horizontal[0] = horizontal.x; c.horizontal[1] = horizontal.y; c.horizontal[2] = horizontal.z;
+    c.vertical[0] = vertical.x; c.vertical[1] = vertical.y; c.vertical[2] = vertical.z;
+    return c;
+}
+
+// ------------------------------------------------------------------ Film (film.cpp:18-23, 59-79)
+Film::Film(int w, int h, int samples, std::string output) : outputName(output) { resize(w, h, samples); }
+void Film::resize(int w, int h, int samples) {
+    f = {w, h, samples};
+    pixels.assign((size_t)w * h * 3, 0);
+    lin.assign((size_t)w * h * 3, 0.0f);
+}
+int Film::outputFilm() {
+    auto ends = [&](const char* suf) { std::string s(suf); return outputName.size() >= s.size() && outputName.compare(outputName.size() - s.size(), s.size(), s) == 0; };
+    if (ends(".png")) return writePNG(outputName, pixels.data(), f.width, f.height, f.width * 3) ? 1 : 0;
+    if (ends(".tga")) return writeTGA(outputName, pixels.data(), f.width, f.height) ? 1 : 0;
+    if (!ends(".bmp")) std::cout << "File type not supported, generating bitmap!" << std::endl;
+    std::cout << ">>> " << outputName << std::endl;
+    return writeBMP(outputName, pixels.data(), f.width, f.height) ? 1 : 0;
+}
+
+void flattenWorld(FlatBuilder& fb, const std::shared_ptr<Hittable>& world, const std::shared_ptr<Texture>& background) {
+    fb.chain.clear();
+    fb.setBackground(background);
+    world->flatten(fb);
+}
+
+}  // namespace hrthost

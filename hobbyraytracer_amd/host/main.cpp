@@ -1,0 +1,98 @@
+// main.cpp — the CLI, drop-in for the reference's executable (main.cpp:142-195):
+//     hobbyraytracer [scene.yaml]
+// Default scene "teapot_scene.yaml" in the cwd, same console lines, same exit
+// code convention (Q-12: the process returns Film::outputFilm()'s int, 1 on
+// success; -1 when the scene fails to load).  Additive flags:
+//     --gpus N   --seed S   --spp N   --size WxH   --quirks reference|fixed
+//     --assets DIR (search dir for meshes / textures)   --stats   --out FILE
+//     --make-assets DIR (write the procedural teapot.obj / marble_bust_01.obj / old_hall_4k.hdr and exit)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <string>
+
+#include "assets.h"
+#include "classes.h"
+#include "render.h"
+
+using namespace hrthost;
+
+constexpr int NUM_THREADS = 12;  // main.cpp:34 (unused by render, as in the reference)
+
+static void printElapsed(const char* what, std::chrono::high_resolution_clock::time_point start) {
+    auto eMS = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - start);
+    unsigned int iH = (unsigned)std::chrono::duration_cast<std::chrono::hours>(eMS).count();
+    unsigned int iM = (unsigned)std::chrono::duration_cast<std::chrono::minutes>(eMS).count() - (iH * 60);
+    long double fS = (eMS.count() / 1000.0) - (double)((iM * 60) + (iH * 3600));
+    std::cout << std::endl << std::setprecision(6) << what << " (completed in " << iH << ":" << iM << ":" << fS << ")" << std::endl;
+}
+
+int main(int argc, char** argv) {
+    auto start = std::chrono::high_resolution_clock::now();
+    std::string file = "teapot_scene.yaml";  // main.cpp:146
+    std::string assets, out, makeAssets;
+    RenderOptions opt;
+    int spp = -1, sw = -1, sh = -1;
+    bool haveFile = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char* flag) -> const char* {
+            if (i + 1 >= argc) { std::cerr << flag << " needs a value" << std::endl; std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--gpus") opt.gpus = std::atoi(next("--gpus"));
+        else if (a == "--seed") opt.seed = std::strtoull(next("--seed"), nullptr, 0);
+        else if (a == "--spp") spp = std::atoi(next("--spp"));
+        else if (a == "--size") { if (std::sscanf(next("--size"), "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH" << std::endl; return 2; } }
+        else if (a == "--quirks") { std::string q = next("--quirks"); opt.quirks = (q == "fixed") ? HRT_QUIRKS_FIXED : HRT_QUIRKS_REFERENCE; }
+        else if (a == "--assets") assets = next("--assets");
+        else if (a == "--out") out = next("--out");
+        else if (a == "--stats") opt.stats = true;
+        else if (a == "--make-assets") makeAssets = next("--make-assets");
+        else if (!haveFile) { file = a; haveFile = true; }
+    }
+    if (!makeAssets.empty()) {
+        long t = writeTeapotObj(makeAssets + "/teapot.obj", 1.0);
+        long b = writeBustObj(makeAssets + "/marble_bust_01.obj", 1.0);
+        bool h = writeHallHdr(makeAssets + "/old_hall_4k.hdr", 4096, 2048);
+        std::cout << "teapot.obj: " << t << " triangles, marble_bust_01.obj: " << b << " triangles, old_hall_4k.hdr: " << (h ? "ok" : "FAILED") << std::endl;
+        return (t > 0 && b > 0 && h) ? 0 : 1;
+    }
+
+    Scene scene;
+    if (scene.loadScene(file, assets) < 1) return -1;  // main.cpp:155-156
+
+    std::shared_ptr<Film> film = scene.getFilm();
+    if (sw > 0 || spp > 0) {
+        film_desc f = film->getFilm();
+        scene.setFilmSize(sw > 0 ? sw : f.width, sh > 0 ? sh : f.height, spp > 0 ? spp : f.samples);
+    }
+    if (!out.empty()) film->setOutput(out);
+    Camera camera = scene.getCamera();
+    std::shared_ptr<Texture> background = scene.getBackground();
+    std::shared_ptr<HittableList> world = scene.getScene();
+
+    printElapsed(("Loaded scene: " + file + "!").c_str(), start);
+
+    hrt_stats stats{};
+    double seconds = 0.0;
+    hrt_status st = render(NUM_THREADS, background, world, camera, film, opt, &stats, &seconds);
+    if (st != HRT_OK) return -1;
+
+    int r = film->outputFilm();
+
+    if (opt.stats || std::getenv("HRT_STATS")) {
+        const double bytes = 32.0 * stats.box_tests + 36.0 * stats.tri_tests + 60.0 * stats.mesh_hits + 12.0 * stats.env_lookups +
+                             12.0 * film->getFilm().width * film->getFilm().height;
+        std::printf("{\"rays\": %llu, \"samples\": %llu, \"box_tests\": %llu, \"tri_tests\": %llu, \"render_s\": %.6f, "
+                    "\"kernel_ms\": %.3f, \"mrays_per_s\": %.3f, \"msamples_per_s\": %.3f, \"algorithmic_gb_per_s\": %.3f}\n",
+                    (unsigned long long)stats.rays, (unsigned long long)stats.samples, (unsigned long long)stats.box_tests,
+                    (unsigned long long)stats.tri_tests, seconds, stats.kernel_ms, stats.rays / seconds / 1e6,
+                    stats.samples / seconds / 1e6, stats.kernel_ms > 0 ? bytes / (stats.kernel_ms * 1e-3) / 1e9 : 0.0);
+    }
+    printElapsed("Done!", start);
+    return r;  // main.cpp:194 (1 = success)
+}

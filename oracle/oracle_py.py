@@ -1,0 +1,140 @@
+"""ctypes wrapper of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product
+package.  See the header of oracle.cpp for what the oracle is and how (un)pinned it is.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hobbyraytracer_amd import api
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+STB_REF_PATH = os.path.join(_HERE, "_ref", "libstbref.so")
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+if not os.path.exists(LIB_PATH):
+    build()
+_lib = C.CDLL(LIB_PATH)
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_lib.oracle_world_create.argtypes = [C.POINTER(api.FlatScene)]
+_lib.oracle_world_create.restype = _vp
+_lib.oracle_world_destroy.argtypes = [_vp]
+_lib.oracle_world_destroy.restype = None
+_lib.oracle_render_tile.argtypes = [_vp, C.POINTER(api.Camera), C.POINTER(api.Params), api.Rect, _fp, C.POINTER(api.Stats), C.c_int]
+_lib.oracle_closest_hit.argtypes = [_vp, C.POINTER(api.Params), C.c_int64, _fp, _fp, C.c_float, C.c_float, C.c_uint32, C.POINTER(api.Hit)]
+_lib.oracle_resolve_u8.argtypes = [_fp, C.c_int64, C.POINTER(C.c_uint8)]
+_lib.oracle_resolve_u8.restype = None
+_lib.oracle_tonemap.argtypes = [_fp, C.c_int64, _fp]
+_lib.oracle_tonemap.restype = None
+_lib.oracle_sphere_uv.argtypes = [_fp, _fp]
+_lib.oracle_sphere_uv.restype = None
+_lib.oracle_math_probe.argtypes = [C.c_int32, C.c_int64, _fp, _fp, _fp]
+_lib.oracle_math_probe.restype = None
+_lib.oracle_spherical_rand.argtypes = [C.c_uint32, C.c_int64, _fp]
+_lib.oracle_spherical_rand.restype = None
+_lib.oracle_ball_rand.argtypes = [C.c_uint32, C.c_int64, _fp]
+_lib.oracle_ball_rand.restype = None
+_lib.oracle_quat_rotate_euler_deg.argtypes = [_fp, _fp, _fp]
+_lib.oracle_quat_rotate_euler_deg.restype = None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp)
+
+
+class World:
+    """The reference's object graph rebuilt from a flat scene (which must outlive this object)."""
+
+    def __init__(self, flat_ptr):
+        self._keep = flat_ptr
+        self._h = _lib.oracle_world_create(flat_ptr)
+
+    def close(self):
+        if self._h:
+            _lib.oracle_world_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def render_tile(self, cam, params, rect=None, threads=None):
+        if rect is None:
+            rect = api.Rect(0, 0, params.width, params.height)
+        elif not isinstance(rect, api.Rect):
+            rect = api.Rect(*rect)
+        out = np.empty((rect.h, rect.w, 3), dtype=np.float32)
+        st = api.Stats()
+        rc = _lib.oracle_render_tile(self._h, C.byref(cam), C.byref(params), rect, _p(out), C.byref(st),
+                                     threads or os.cpu_count() or 1)
+        if rc != 0:
+            raise RuntimeError("oracle_render_tile failed")
+        return out, st
+
+    def closest_hit(self, params, origins, dirs, t_min=0.001, t_max=float("inf"), pixel0=0):
+        o, d = _f32(origins), _f32(dirs)
+        n = o.shape[0]
+        out = np.zeros(n, dtype=api.HIT_DTYPE)
+        _lib.oracle_closest_hit(self._h, C.byref(params), n, _p(o), _p(d), t_min, t_max, pixel0, out.ctypes.data_as(C.POINTER(api.Hit)))
+        return out
+
+
+def resolve_u8(rgb):
+    a = _f32(rgb)
+    out = np.empty(a.shape, dtype=np.uint8)
+    _lib.oracle_resolve_u8(_p(a), a.size // 3, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def tonemap(rgb):
+    a = _f32(rgb)
+    out = np.empty_like(a)
+    _lib.oracle_tonemap(_p(a), a.size // 3, _p(out))
+    return out
+
+
+def sphere_uv(p):
+    a = _f32(p)
+    out = np.empty(2, dtype=np.float32)
+    _lib.oracle_sphere_uv(_p(a), _p(out))
+    return out
+
+
+def math_probe(op, a, b=None):
+    a = _f32(a)
+    n = a.size // 4 if op == 5 else a.size
+    out = np.empty(n * 4 if op == 5 else n, dtype=np.float32)
+    bb = _f32(b) if b is not None else None
+    _lib.oracle_math_probe(op, n, _p(a), _p(bb) if bb is not None else None, _p(out))
+    return out
+
+
+def spherical_rand(seed, n):
+    out = np.empty((n, 3), dtype=np.float32)
+    _lib.oracle_spherical_rand(seed, n, _p(out))
+    return out
+
+
+def ball_rand(seed, n):
+    out = np.empty((n, 3), dtype=np.float32)
+    _lib.oracle_ball_rand(seed, n, _p(out))
+    return out
+
+
+def quat_rotate_euler_deg(euler_deg, v):
+    out = np.empty(3, dtype=np.float32)
+    _lib.oracle_quat_rotate_euler_deg(_p(_f32(euler_deg)), _p(_f32(v)), _p(out))
+    return out
