@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the MI355X path tracer on the headline workload of BASELINE.json:
+teapot_scene.yaml, 640x640, 100 spp (procedural stand-ins for the missing teapot.obj and
+old_hall_4k.hdr), reference quirks, seed 0.
+
+One "step" = one whole frame: path-trace kernel over this rank's interleaved row blocks, gather of the
+fp32 linear film tiles (RCCL all_gather when N > 1), row permutation and Film resolve (tonemap -> u8)
+on rank 0's copy.  Inputs (scene, BVH, env map) are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the path-trace kernel: algorithmic bytes per launch (SURVEY.md §8(d) prices, counted
+                 exactly by the STATS build of the same kernel on the same seed) / average launch
+                 duration measured with HIP events recorded on the launch stream around each launch.
+  cpu_baseline — the CPU oracle (a port: the reference binary cannot be built) timed on
+                 this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def host_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("HRT_CPU_THREADS")
+    if env:
+        n = max(1, int(env))
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=640)
+    ap.add_argument("--spp", type=int, default=100)
+    ap.add_argument("--scene", default="teapot_scene.yaml", help="file name under tests/golden/scenes")
+    ap.add_argument("--quirks", choices=["reference", "fixed"], default="reference")
+    ap.add_argument("--rows-per-block", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from hobbyraytracer_amd import api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: procedural assets + scene load + flatten + upload (all untimed)
+    tmp = tempfile.mkdtemp(prefix=f"hrt_bench_r{rank}_")
+    api.write_teapot_obj(os.path.join(tmp, "teapot.obj"), 1.0)
+    api.write_hall_hdr(os.path.join(tmp, "old_hall_4k.hdr"), 4096, 2048)
+    hs = api.HostScene(os.path.join(ROOT, "tests", "golden", "scenes", args.scene), tmp)
+    W, H, spp = args.width, args.height, args.spp
+    cam = hs.camera(W, H)
+    quirks = api.QUIRKS_REFERENCE if args.quirks == "reference" else api.QUIRKS_FIXED
+    params = api.default_params(W, H, spp, quirks=quirks, seed=0)
+    params_stats = api.default_params(W, H, spp, quirks=quirks, seed=0, stats=True)
+    dev = api.DeviceScene(hs.flat_ptr, local_rank)
+
+    R = args.rows_per_block
+    my_rows = api.stripe_rows(H, R, rank, world)
+    rows_per_rank = [api.stripe_rows(H, R, r, world) for r in range(world)]
+    max_rows = max(rows_per_rank)
+    tile = torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda")
+    gathered = torch.zeros((world, max_rows, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
+    # permutation: film row -> (rank, local row) flattened index into `gathered`
+    perm = np.zeros(H, dtype=np.int64)
+    for r in range(world):
+        idx = api.stripe_row_indices(H, R, r, world)
+        perm[idx] = r * max_rows + np.arange(len(idx))
+    perm_t = torch.from_numpy(perm).cuda()
+    film_lin = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    film_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(p):
+        dev.render_stripes_device(cam, p, R, rank, world, tile.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, tile)
+            src = gathered.view(world * max_rows, W, 3)
+        else:
+            src = tile
+        if rank == 0:
+            torch.index_select(src, 0, perm_t, out=film_lin)
+            dev.resolve_u8_device(film_lin.data_ptr(), W * H, film_u8.data_ptr(), stream)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- counting launch (untimed): exact algorithmic bytes of one launch of this rank
+    step(params_stats)
+    sync()
+    st_count = dev.stats()
+    alg_bytes_launch = st_count.algorithmic_bytes(my_rows * W)
+
+    for _ in range(args.warmup):
+        step(params)
+    sync()
+    dev.stats()  # clear counters / kernel timers
+
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(params)
+    sync()
+    t1 = time.perf_counter()
+    st = dev.stats()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([float(st.rays), float(st.samples), float(alg_bytes_launch)], dtype=torch.float64, device="cuda")
+    kern = torch.tensor([st.kernel_ms / max(1, st.launches)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        kern_max = kern.clone()
+        dist.all_reduce(kern_max, op=dist.ReduceOp.MAX)
+    else:
+        kern_max = kern
+    seconds = float(elapsed.item())
+    total_rays, total_samples, total_bytes_launch = [float(x) for x in counts.tolist()]
+    kernel_ms = float(kern_max.item())
+
+    if rank == 0:
+        ms_per_step = seconds / args.steps * 1e3
+        mrays = total_rays / seconds / 1e6
+        # roofline of the dominant kernel (k_pathtrace) on rank 0's device
+        achieved = alg_bytes_launch / (float(kern.item()) * 1e-3) / 1e9
+        result = {
+            "metric": "Mrays/sec (path segments/s), teapot_scene.yaml 640x640 100spp",
+            "value": round(mrays, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (procedural teapot.obj ~6.2k tris + procedural 4096x2048 old_hall_4k.hdr stand-ins; seed 0)",
+            "config": {"workload": f"{args.scene} {W}x{H} {spp}spp, quirks={args.quirks}, max_depth=50",
+                       "parallelism": f"image row blocks of {R} rows interleaved over {world} GPU(s); RCCL all_gather of fp32 film tiles" if world > 1 else "single GPU",
+                       "rays_per_step": total_rays / args.steps, "samples_per_step": total_samples / args.steps,
+                       "msamples_per_s": round(total_samples / seconds / 1e6, 3),
+                       "wall_clock_s_per_frame": round(seconds / args.steps, 6),
+                       "reference_readme_wall_clock_s": 150.0},
+            "roofline": {"bound": "hbm", "kernel": "k_pathtrace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch, "kernel_ms_per_launch": round(float(kern.item()), 4),
+                         "box_tests_per_ray": round(st_count.box_tests / max(1, st_count.rays), 3),
+                         "tri_tests_per_ray": round(st_count.tri_tests / max(1, st_count.rays), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
+            from oracle import oracle_py as orc
+            cores = host_cores()
+            cp = api.default_params(W, H, args.cpu_spp, quirks=quirks, seed=0)
+            wd = orc.World(hs.flat_ptr)
+            c0 = time.perf_counter()
+            _, cst = wd.render_tile(cam, cp, threads=cores)
+            c1 = time.perf_counter()
+            cpu_mrays = cst.rays / (c1 - c0) / 1e6
+            result["cpu_baseline"] = {"value": round(cpu_mrays, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                      "sample": f"same scene and film {W}x{H} at {args.cpu_spp} spp (of {spp}), {cst.rays} segments in {c1 - c0:.2f} s, std::thread over rows"}
+            result["config"]["gpu_over_cpu"] = round(mrays / cpu_mrays, 2)
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,7 @@ class FlatScene(C.Structure):
                 ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture)),
                 ("n_meshes", C.c_uint32), ("meshes", C.POINTER(Mesh)),
                 ("n_tris", C.c_uint64), ("tri_pos", C.POINTER(C.c_float)), ("tri_nrm", C.POINTER(C.c_float)),
-                ("tri_uv", C.POINTER(C.c_float)), ("tri_box", C.POINTER(C.c_float)),
+                ("tri_uv", C.POINTER(C.c_float)), ("tri_box", C.POINTER(C.c_float)), ("tri_ref_order", C.POINTER(C.c_uint32)),
                 ("n_nodes", C.c_uint64), ("nodes", C.POINTER(BvhNode)),
                 ("n_texels_u8", C.c_uint64), ("texels_u8", C.POINTER(C.c_uint8)),
                 ("n_texels_f32", C.c_uint64), ("texels_f32", C.POINTER(C.c_float)),

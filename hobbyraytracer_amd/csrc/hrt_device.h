@@ -303,6 +303,21 @@ __device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 
     const float ox = o.x * idx, oy = o.y * idy, oz = o.z * idz;
     float closest = t_max;
     int best = -1;
+    // Culling interval [t_lo, closest].  With Q-2 the reference accepts triangle hits at any t > 0 as long
+    // as the boxes of ITS tree pass [t_min, t_max]; those boxes are not the ones of this tree, so cull
+    // from 0 (every t > 0 candidate is then reached) and let accept_box apply the reference's own
+    // leaf-level box afterwards.
+    const float t_lo = (quirks & HRT_Q2_TRI_NO_TMIN) ? 0.0f : t_min;
+    // Self-hits (Q-2): a candidate with t < t_min.  In the reference, once one is accepted every later
+    // BOX test fails (bvh.cpp:71 gets t_max = rec.t < t_min), so the one in the FIRST lowest-level node of
+    // its own tree's depth-first walk wins, whatever its distance (the two triangles of that one node are
+    // both tested, bvh.cpp:74-75).  Here: after the first self-hit the interval shrinks to
+    // [0, t_min+] -- only boxes that close to the origin can hold another self-hit -- and candidates are
+    // ranked by hrt_flat_scene::tri_ref_order.
+    bool selfhit = false;
+    uint32_t self_order = 0xffffffffu;
+    int self_tri = -1;
+    float self_t = 0.0f;
     int sp = 0;
     int cur = 0;  // root
     const int SENTINEL = 0x7fffffff;
@@ -318,16 +333,16 @@ __device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 
             float a0 = fmaf(n0.x, idx, -ox), a1 = fmaf(n0.y, idx, -ox);
             float b0 = fmaf(n0.z, idy, -oy), b1 = fmaf(n0.w, idy, -oy);
             float c0 = fmaf(n2.x, idz, -oz), c1 = fmaf(n2.y, idz, -oz);
-            float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_min));
+            float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_lo));
             float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), closest));
             // child 1
             float e0 = fmaf(n1.x, idx, -ox), e1 = fmaf(n1.y, idx, -ox);
             float f0 = fmaf(n1.z, idy, -oy), f1 = fmaf(n1.w, idy, -oy);
             float g0 = fmaf(n2.z, idz, -oz), g1 = fmaf(n2.w, idz, -oz);
-            float tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_min));
+            float tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_lo));
             float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), closest));
-            const bool h0 = tn0 < tf0;   // aabb.h:35: t_max <= t_min rejects
-            const bool h1 = tn1 < tf1;
+            const bool h0 = tn0 <= tf0;
+            const bool h1 = tn1 <= tf1;
             const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
             if (h0 && h1) {
                 const bool swap = tn1 < tn0;
@@ -353,14 +368,27 @@ __device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 
                 const float invDet = 1 / ev.det;
                 const float t = ev.tScaled * invDet;
                 if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
-                if (!accept_box(tbox[2 * ti], tbox[2 * ti + 1], o, d, t_min, closest)) continue;
-                closest = t;
-                best = (int)ti;
+                const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
+                if (!accept_box(bmn, bmx, o, d, t_min, closest)) continue;
+                if (t < t_min) {
+                    const uint32_t ord = (uint32_t)__float_as_int(bmn.w);
+                    bool take;
+                    if (!selfhit) take = true;
+                    else if ((ord >> 1) != (self_order >> 1)) take = (ord >> 1) < (self_order >> 1);
+                    else if (ord & 1u) take = !(t > self_t);   // this is `right`, the kept one is `left`: bvh.cpp:75
+                    else take = self_t > t;                     // this is `left`: `right` survives only if not farther
+                    if (take) { self_order = ord; self_tri = (int)ti; self_t = t; }
+                    if (!selfhit) { selfhit = true; closest = t_min * 1.0001f; }
+                } else if (!selfhit) {
+                    closest = t;
+                    best = (int)ti;
+                }
             }
             if (sp > 0) { --sp; cur = stack[sp * HRT_BLOCK]; }
             else cur = SENTINEL;
         }
     }
+    if (selfhit) { t_out = self_t; return self_tri; }
     t_out = closest;
     return best;
 }
@@ -554,6 +582,60 @@ __device__ inline vec3 background_value(const DScene& sc, vec3 d) {
     float u = phi / (2 * pi) + 0.5f;
     float v = theta / pi;
     return tex_value(sc, sc.background_tex, u, v, vec3(0.0f));
+}
+
+// ------------------------------------------------------------------ render() / rayColour() pieces (main.cpp)
+struct PathState {
+    vec3 o, d;          // current ray
+    vec3 atten, result; // currentAttenuation, result (main.cpp:40-41)
+    int bounce;
+};
+struct PathCounters {
+    unsigned rays, samples, mesh_hits, env_lookups;
+    DCounters bvh;
+};
+
+// main.cpp:115-123 + Camera::getRay (camera.h:29-39): starts sample `ctx.sample` of pixel (px, py).
+__device__ inline void path_begin(const hrt_camera& cam, const hrt_params& pr, int px, int py, rng_ctx& ctx, PathState& ps) {
+    const vec3 c_origin(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const vec3 c_llc(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
+    const vec3 c_hor(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    const vec3 c_ver(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    ctx.bounce = 0;
+    const u32x4 j = rng_draw(ctx, RNG_JITTER, 0);
+    const int x = px;                 // main.cpp:115 (pIdx % W)
+    const int y = pr.height - py;     // main.cpp:116 (H - pIdx / W), Q-10
+    const float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (pr.width - 1);
+    const float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (pr.height - 1);
+    ps.o = c_origin;
+    ps.d = c_llc + u * c_hor + v * c_ver - c_origin;
+    ps.atten = vec3(1.0f); ps.result = vec3(0.0f); ps.bounce = 0;
+}
+
+// One iteration of the loop at main.cpp:43-76.  Returns true when the path has ended
+// (miss, emitter / absorbed, or MAX_DEPTH segments traced).
+template <bool STATS>
+__device__ inline bool path_segment(const DScene& sc, const hrt_params& pr, rng_ctx& ctx, PathState& ps, int* stack,
+                                    PathCounters& pc) {
+    ctx.bounce = (uint32_t)ps.bounce;
+    pc.rays++;
+    const WorldHit wh = world_hit<STATS>(sc, ps.o, ps.d, pr.t_min, __builtin_huge_valf(), pr.quirks, ctx, stack, pc.bvh);
+    if (wh.prim < 0) {
+        if (STATS && sc.texs[sc.background_tex].kind == HRT_TEX_ENV) pc.env_lookups++;
+        ps.result += ps.atten * background_value(sc, ps.d);
+        return true;
+    }
+    if (STATS && sc.prims[wh.prim].kind == HRT_PRIM_MESH) pc.mesh_hits++;
+    DRec rec;
+    world_rec(sc, wh, ps.o, ps.d, pr.quirks, rec);
+    vec3 emitted, attenuation, so, sd;
+    const bool b = material_scatter(sc, rec, ps.d, ctx, emitted, attenuation, so, sd);
+    ps.result += ps.atten * emitted;
+    if (!b) return true;
+    ps.atten *= attenuation;
+    ps.o = so; ps.d = sd;
+    ps.bounce++;
+    return ps.bounce >= pr.max_depth;
 }
 
 // film.cpp:32-52 + 25-30

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "hrt_device.h"
+#include "hrt_pack.h"
 
 using namespace hrt;
 
@@ -54,12 +55,6 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_pathtrace(DScene sc, hrt_camera c
     int* stack = s_stack + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
 
-    const vec3 c_origin(cam.origin[0], cam.origin[1], cam.origin[2]);
-    const vec3 c_llc(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
-    const vec3 c_hor(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
-    const vec3 c_ver(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
-    const float INF = __builtin_huge_valf();
-
     // lane state
     int out_index = -1;          // local pixel (row-major in the region); -1 = lane holds no pixel
     int px = 0, py = 0;          // absolute pixel
@@ -67,10 +62,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_pathtrace(DScene sc, hrt_camera c
     int s = 0;
     bool new_sample = false;
     bool exhausted = false;
-    vec3 sum(0.0f), o(0.0f), d(0.0f), atten(1.0f), result(0.0f);
-    int bounce = 0;
-    unsigned n_rays = 0, n_samples = 0, n_mesh = 0, n_env = 0;
-    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+    vec3 sum(0.0f);
+    PathState ps; ps.o = vec3(0.0f); ps.d = vec3(0.0f); ps.atten = vec3(1.0f); ps.result = vec3(0.0f); ps.bounce = 0;
+    PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
 
     for (;;) {
         // ---- refill: lanes without a pixel draw work items (one atomic per wave)
@@ -102,47 +96,11 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_pathtrace(DScene sc, hrt_camera c
         if (__ballot((out_index >= 0) || !exhausted) == 0ull) break;
 
         if (out_index >= 0) {
-            rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi; ctx.pixel = pidx; ctx.sample = (uint32_t)s;
-            if (new_sample) {
-                // main.cpp:115-123 + Camera::getRay (camera.h:29-39)
-                ctx.bounce = 0;
-                const u32x4 j = rng_draw(ctx, RNG_JITTER, 0);
-                const int x = px;
-                const int y = pr.height - py;
-                const float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (pr.width - 1);
-                const float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (pr.height - 1);
-                o = c_origin;
-                d = c_llc + u * c_hor + v * c_ver - c_origin;
-                atten = vec3(1.0f); result = vec3(0.0f); bounce = 0; new_sample = false;
-                n_samples++;
-            }
-            // ---- one path segment: the body of the loop at main.cpp:43-76
-            ctx.bounce = (uint32_t)bounce;
-            n_rays++;
-            const WorldHit wh = world_hit<STATS>(sc, o, d, pr.t_min, INF, pr.quirks, ctx, stack, cnt);
-            bool ended;
-            if (wh.prim < 0) {
-                if (STATS && sc.texs[sc.background_tex].kind == HRT_TEX_ENV) n_env++;
-                result += atten * background_value(sc, d);
-                ended = true;
-            } else {
-                if (STATS && sc.prims[wh.prim].kind == HRT_PRIM_MESH) n_mesh++;
-                DRec rec;
-                world_rec(sc, wh, o, d, pr.quirks, rec);
-                vec3 emitted, attenuation, so, sd;
-                const bool b = material_scatter(sc, rec, d, ctx, emitted, attenuation, so, sd);
-                result += atten * emitted;
-                if (!b) {
-                    ended = true;
-                } else {
-                    atten *= attenuation;
-                    o = so; d = sd;
-                    bounce++;
-                    ended = bounce >= pr.max_depth;
-                }
-            }
+            rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi; ctx.pixel = pidx; ctx.sample = (uint32_t)s; ctx.bounce = 0;
+            if (new_sample) { path_begin(cam, pr, px, py, ctx, ps); new_sample = false; pc.samples++; }
+            const bool ended = path_segment<STATS>(sc, pr, ctx, ps, stack, pc);
             if (ended) {
-                sum += result;
+                sum += ps.result;     // main.cpp:123
                 s++;
                 new_sample = true;
                 if (s >= pr.samples) {
@@ -156,9 +114,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_pathtrace(DScene sc, hrt_camera c
     }
 
     // ---- counters: one 64-bit atomic per wave per counter
-    const unsigned r = wave_sum(n_rays), sm = wave_sum(n_samples);
+    const unsigned r = wave_sum(pc.rays), sm = wave_sum(pc.samples);
     unsigned bt = 0, tt = 0, mh = 0, ev = 0;
-    if (STATS) { bt = wave_sum(cnt.box_tests); tt = wave_sum(cnt.tri_tests); mh = wave_sum(n_mesh); ev = wave_sum(n_env); }
+    if (STATS) { bt = wave_sum(pc.bvh.box_tests); tt = wave_sum(pc.bvh.tri_tests); mh = wave_sum(pc.mesh_hits); ev = wave_sum(pc.env_lookups); }
     if (lane == 0) {
         atomicAdd(&counters->rays, (unsigned long long)r);
         atomicAdd(&counters->samples, (unsigned long long)sm);
@@ -475,30 +433,9 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     float4* d_nodes;
     UP(d_nodes, f->nodes, sizeof(hrt_bvh_node) * f->n_nodes);
 
-    // repack triangles into 16-byte aligned records
-    const size_t nt = (size_t)f->n_tris;
-    std::vector<float> pos(nt * 12), attr(nt * 16), box(nt * 8);
-    for (size_t i = 0; i < nt; ++i) {
-        const float* p = f->tri_pos + 9 * i; const float* n = f->tri_nrm + 9 * i; const float* uv = f->tri_uv + 6 * i;
-        for (int k = 0; k < 3; ++k) { pos[12 * i + 4 * k] = p[3 * k]; pos[12 * i + 4 * k + 1] = p[3 * k + 1]; pos[12 * i + 4 * k + 2] = p[3 * k + 2]; pos[12 * i + 4 * k + 3] = 0.0f; }
-        float* a = &attr[16 * i];
-        a[0] = n[0]; a[1] = n[1]; a[2] = n[2]; a[3] = uv[0];
-        a[4] = n[3]; a[5] = n[4]; a[6] = n[5]; a[7] = uv[1];
-        a[8] = n[6]; a[9] = n[7]; a[10] = n[8]; a[11] = uv[2];
-        a[12] = uv[3]; a[13] = uv[4]; a[14] = uv[5]; a[15] = 0.0f;
-        float* b = &box[8 * i];
-        if (f->tri_box) {
-            const float* s = f->tri_box + 6 * i;
-            b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[3] = 0.0f; b[4] = s[3]; b[5] = s[4]; b[6] = s[5]; b[7] = 0.0f;
-        } else {  // triangle.cpp:133-151
-            for (int c = 0; c < 3; ++c) {
-                float mn = gmin(gmin(p[c], p[3 + c]), p[6 + c]);
-                float mx = gmax(gmax(p[c], p[3 + c]), p[6 + c]);
-                b[c] = mn - 0.0001f; b[4 + c] = mx + 0.0001f;
-            }
-            b[3] = b[7] = 0.0f;
-        }
-    }
+    // repack triangles into 16-byte aligned records (hrt_pack.h)
+    std::vector<float> pos, attr, box;
+    pack_triangles(f, pos, attr, box);
     float4 *d_pos, *d_attr, *d_box;
     UP(d_pos, pos.data(), pos.size() * sizeof(float));
     UP(d_attr, attr.data(), attr.size() * sizeof(float));

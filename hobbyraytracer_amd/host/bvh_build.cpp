@@ -9,9 +9,11 @@
 // around a triangle is the one of its lowest BVHNode (itself for a 1-object
 // node, the union with its sibling for a 2-object node; bvh.cpp:20-36,52-60).
 // referenceLeafBoxes() restates that build to obtain those boxes; the kernel
-// applies them to accepted candidates (hrt_device.h accept_box), and the SAH
-// tree's boxes are refitted to CONTAIN them, so culling in the flattened tree
-// can never remove a triangle the reference would have accepted.
+// applies them to accepted candidates (hrt_device.h accept_box).  The SAH
+// tree's own boxes stay tight (union of the padded triangle boxes): the kernel
+// culls with the interval [0, closest] when Q-2 is on, so every candidate with
+// t > 0 is reached whatever the reference's boxes look like, and accept_box
+// then decides exactly as the reference would.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -50,7 +52,7 @@ Box3 paddedTriBox(const float* p) {
 
 // bvh.cpp:6-61 restated for topology only.  `order` holds triangle indices.
 void refBuild(std::vector<uint32_t>& order, size_t start, size_t end, const std::vector<Box3>& boxes, uint32_t& serial,
-              std::vector<float>& out) {
+              std::vector<float>& out, std::vector<uint32_t>& leafOrder) {
     hrt::u32x4 u = hrt::philox4x32_10(serial++, 0, 0, hrt::RNG_BUILD, 0, 0);  // bvh.cpp:10
     const int a = (int)(u.x % 3u);
     auto comparator = [&](uint32_t x, uint32_t y) { return boxes[x].mn[a] < boxes[y].mn[a]; };  // bvh.cpp:80-90
@@ -61,20 +63,25 @@ void refBuild(std::vector<uint32_t>& order, size_t start, size_t end, const std:
     if (n == 1) {
         // left = right = obj ; box = surroundingBox(b, b) = b
         store(order[start], boxes[order[start]]);
+        leafOrder[order[start]] = (uint32_t)(start << 1);
     } else if (n == 2) {
         Box3 b;
         for (int k = 0; k < 3; ++k) {  // AABB::surroundingBox (aabb.h:41-56, glm::min / glm::max)
             b.mn[k] = hrt::gmin(boxes[order[start]].mn[k], boxes[order[start + 1]].mn[k]);
             b.mx[k] = hrt::gmax(boxes[order[start]].mx[k], boxes[order[start + 1]].mx[k]);
         }
-        // (the comparator call of bvh.cpp:26 only orders left/right; it draws nothing)
+        // bvh.cpp:26-36: left = the lesser on the chosen axis, so the walk order inside the pair may swap
+        const bool keep = comparator(order[start], order[start + 1]);
         store(order[start], b);
         store(order[start + 1], b);
+        // code = (leaf-level node id << 1) | side, side 0 = `left` (tested first), 1 = `right`
+        leafOrder[order[start]] = (uint32_t)((start << 1) | (keep ? 0u : 1u));
+        leafOrder[order[start + 1]] = (uint32_t)((start << 1) | (keep ? 1u : 0u));
     } else if (n != 0) {
         std::sort(order.begin() + start, order.begin() + end, comparator);  // bvh.cpp:39
         const size_t mid = start + n / 2;
-        refBuild(order, start, mid, boxes, serial, out);
-        refBuild(order, mid, end, boxes, serial, out);
+        refBuild(order, start, mid, boxes, serial, out, leafOrder);
+        refBuild(order, mid, end, boxes, serial, out, leafOrder);
     }
 }
 
@@ -121,7 +128,7 @@ struct SahBuilder {
                 const float scale = NB / e;
                 for (uint32_t i = lo; i < hi; ++i) {
                     int k = (int)((refs[i].c[a] - cb.mn[a]) * scale);
-                    if (k < 0) k = 0; if (k >= NB) k = NB - 1;
+                    k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
                     bb[k].grow(refs[i].b); bc[k]++;
                 }
                 float rightArea[NB]; uint32_t rightCount[NB];
@@ -143,7 +150,7 @@ struct SahBuilder {
                 const float scale = 16 / e;
                 auto it = std::partition(refs.begin() + lo, refs.begin() + hi, [&](const Ref& r) {
                     int k = (int)((r.c[bestAxis] - cb.mn[bestAxis]) * scale);
-                    if (k < 0) k = 0; if (k >= 16) k = 15;
+                    k = k < 0 ? 0 : (k >= 16 ? 15 : k);
                     return k <= bestBin;
                 });
                 mid = (uint32_t)(it - refs.begin());
@@ -176,18 +183,17 @@ void emptyChild(hrt_bvh_node& n, int c) {
     else { n.c1_min_x = n.c1_min_y = n.c1_min_z = inf; n.c1_max_x = n.c1_max_y = n.c1_max_z = -inf; n.child1 = -1; }
 }
 
-// Refit: every child box becomes the union of the acceptance boxes of the
-// triangles below it, widened by a rounding guard so that the fma-based slab
-// test of the kernel can never be tighter than the division-based reference test.
-Box3 refit(std::vector<hrt_bvh_node>& nodes, int32_t ref, const std::vector<float>& leafBoxes, int depth, int& maxDepth) {
+// Refit: every child box becomes the union of the padded ITriangle boxes
+// (triangle.cpp:133-151) of the triangles below it, widened by a rounding guard
+// so that the fma-based slab test of the kernel can never be tighter than a
+// division-based test of the same box.
+Box3 refit(std::vector<hrt_bvh_node>& nodes, int32_t ref, const std::vector<float>& pos, int depth, int& maxDepth) {
     Box3 b; b.reset();
     if (ref < 0) {
         const uint32_t enc = (uint32_t)~ref;
         const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
         for (uint32_t k = 0; k < count; ++k) {
-            Box3 t;
-            for (int a = 0; a < 3; ++a) { t.mn[a] = leafBoxes[6 * (first + k) + a]; t.mx[a] = leafBoxes[6 * (first + k) + 3 + a]; }
-            b.grow(t);
+            b.grow(paddedTriBox(&pos[9 * (first + k)]));
         }
         return b;
     }
@@ -202,12 +208,12 @@ Box3 refit(std::vector<hrt_bvh_node>& nodes, int32_t ref, const std::vector<floa
     };
     const bool e0 = n.c0_min_x > n.c0_max_x, e1 = n.c1_min_x > n.c1_max_x;
     if (!e0) {
-        Box3 c = refit(nodes, n.child0, leafBoxes, depth + 1, maxDepth);
+        Box3 c = refit(nodes, n.child0, pos, depth + 1, maxDepth);
         b.grow(c); c = guard(c);
         n.c0_min_x = c.mn[0]; n.c0_max_x = c.mx[0]; n.c0_min_y = c.mn[1]; n.c0_max_y = c.mx[1]; n.c0_min_z = c.mn[2]; n.c0_max_z = c.mx[2];
     }
     if (!e1) {
-        Box3 c = refit(nodes, n.child1, leafBoxes, depth + 1, maxDepth);
+        Box3 c = refit(nodes, n.child1, pos, depth + 1, maxDepth);
         b.grow(c); c = guard(c);
         n.c1_min_x = c.mn[0]; n.c1_max_x = c.mx[0]; n.c1_min_y = c.mn[1]; n.c1_max_y = c.mx[1]; n.c1_min_z = c.mn[2]; n.c1_max_z = c.mx[2];
     }
@@ -217,16 +223,20 @@ Box3 refit(std::vector<hrt_bvh_node>& nodes, int32_t ref, const std::vector<floa
 }  // namespace
 
 // Restates bvh.cpp:6-61 over the soup (in its CURRENT order) and returns, per
-// triangle, the box of its lowest BVHNode.
-std::vector<float> referenceLeafBoxes(const TriangleSoup& soup) {
+// triangle, the box of its lowest BVHNode and (leafOrder) a code
+// (node << 1) | side: `node` numbers the lowest BVHNodes in the tree's
+// left-to-right order, `side` says whether the triangle is that node's `left`
+// (0, tested first) or `right` (1) child (bvh.cpp:20-36).
+std::vector<float> referenceLeafBoxes(const TriangleSoup& soup, std::vector<uint32_t>& leafOrder) {
     const size_t n = soup.size();
     std::vector<Box3> boxes(n);
     for (size_t i = 0; i < n; ++i) boxes[i] = paddedTriBox(&soup.pos[9 * i]);
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
     std::vector<float> out(6 * n);
+    leafOrder.assign(n, 0);
     uint32_t serial = 0;
-    if (n) refBuild(order, 0, n, boxes, serial, out);
+    if (n) refBuild(order, 0, n, boxes, serial, out, leafOrder);
     return out;
 }
 
@@ -268,9 +278,9 @@ BVHNode::BVHNode(TriangleSoup& soup) {
     }
     soup = std::move(re);
     nodes = std::move(sb.nodes);
-    leafBoxes = referenceLeafBoxes(soup);
+    leafBoxes = referenceLeafBoxes(soup, refOrder);
     int md = 1;
-    refit(nodes, 0, leafBoxes, 1, md);
+    refit(nodes, 0, soup.pos, 1, md);
     depth = md;
 }
 

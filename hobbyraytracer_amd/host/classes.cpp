@@ -40,7 +40,7 @@ int FlatBuilder::addMaterial(const std::shared_ptr<Material>& m) {
     return id;
 }
 int FlatBuilder::addMesh(const std::vector<float>& pos, const std::vector<float>& nrm, const std::vector<float>& uv,
-                         const std::vector<float>& box, const std::vector<hrt_bvh_node>& nd) {
+                         const std::vector<float>& box, const std::vector<uint32_t>& refOrder, const std::vector<hrt_bvh_node>& nd) {
     hrt_mesh m{};
     m.tri_first = (uint32_t)(tri_pos.size() / 9);
     m.tri_count = (uint32_t)(pos.size() / 9);
@@ -50,6 +50,7 @@ int FlatBuilder::addMesh(const std::vector<float>& pos, const std::vector<float>
     tri_nrm.insert(tri_nrm.end(), nrm.begin(), nrm.end());
     tri_uv.insert(tri_uv.end(), uv.begin(), uv.end());
     tri_box.insert(tri_box.end(), box.begin(), box.end());
+    tri_ref_order.insert(tri_ref_order.end(), refOrder.begin(), refOrder.end());
     nodes.insert(nodes.end(), nd.begin(), nd.end());
     meshes.push_back(m);
     return (int)meshes.size() - 1;
@@ -63,6 +64,7 @@ hrt_flat_scene FlatBuilder::flat() const {
     f.n_tris = tri_pos.size() / 9;
     f.tri_pos = tri_pos.data(); f.tri_nrm = tri_nrm.data(); f.tri_uv = tri_uv.data();
     f.tri_box = tri_box.size() == 6 * f.n_tris && f.n_tris ? tri_box.data() : nullptr;
+    f.tri_ref_order = tri_ref_order.size() == f.n_tris && f.n_tris ? tri_ref_order.data() : nullptr;
     f.n_nodes = nodes.size(); f.nodes = nodes.data();
     f.n_texels_u8 = texels_u8.size(); f.texels_u8 = texels_u8.data();
     f.n_texels_f32 = texels_f32.size(); f.texels_f32 = texels_f32.data();
@@ -204,7 +206,7 @@ Mesh::Mesh(TriangleSoup s, std::shared_ptr<Material> m) : soup(std::move(s)), ma
 }
 void Mesh::flatten(FlatBuilder& fb) const {
     hrt_prim p = basePrim(fb, HRT_PRIM_MESH, matPtr);
-    p.mesh = fb.addMesh(soup.pos, soup.nrm, soup.uv, tree->leafBoxes, tree->nodes);
+    p.mesh = fb.addMesh(soup.pos, soup.nrm, soup.uv, tree->leafBoxes, tree->refOrder, tree->nodes);
     fb.addPrim(p);
 }
 

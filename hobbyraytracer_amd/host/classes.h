@@ -43,7 +43,7 @@ public:
     int addMaterial(const std::shared_ptr<Material>& m);
     // appends a triangle soup + its flattened BVH; returns the mesh index
     int addMesh(const std::vector<float>& pos, const std::vector<float>& nrm, const std::vector<float>& uv,
-                const std::vector<float>& box, const std::vector<hrt_bvh_node>& nodes);
+                const std::vector<float>& box, const std::vector<uint32_t>& refOrder, const std::vector<hrt_bvh_node>& nodes);
     void addPrim(const hrt_prim& p) { prims.push_back(p); }
     uint64_t addTexelsU8(const std::vector<uint8_t>& d) { uint64_t o = texels_u8.size(); texels_u8.insert(texels_u8.end(), d.begin(), d.end()); return o; }
     uint64_t addTexelsF32(const std::vector<float>& d) { uint64_t o = texels_f32.size(); texels_f32.insert(texels_f32.end(), d.begin(), d.end()); return o; }
@@ -57,6 +57,7 @@ public:
     std::vector<hrt_texture> textures;
     std::vector<hrt_mesh> meshes;
     std::vector<float> tri_pos, tri_nrm, tri_uv, tri_box;
+    std::vector<uint32_t> tri_ref_order;
     std::vector<hrt_bvh_node> nodes;
     std::vector<uint8_t> texels_u8;
     std::vector<float> texels_f32;
@@ -266,6 +267,7 @@ public:
     void flatten(FlatBuilder&) const override { throw FlattenError(HRT_ERR_UNSUPPORTED, "BVHNode is flattened through its Mesh"); }
     std::vector<hrt_bvh_node> nodes;
     std::vector<float> leafBoxes;  // 6 floats per triangle: reference leaf-level boxes (hrt_flat_scene::tri_box)
+    std::vector<uint32_t> refOrder; // per triangle: position in the reference tree's leaf order (tri_ref_order)
     int depth = 0;
 };
 

@@ -289,7 +289,7 @@ bool loadImageRGB8(const std::string& path, std::vector<uint8_t>& rgb, int& w, i
         rgb.resize(f.size());
         for (size_t i = 0; i < f.size(); ++i) {
             float z = std::pow(f[i], 1.0f / 2.2f) * 255.0f + 0.5f;
-            if (z < 0) z = 0; if (z > 255) z = 255;
+            z = z < 0 ? 0 : (z > 255 ? 255 : z);
             rgb[i] = (uint8_t)(int)z;
         }
         return true;

@@ -166,6 +166,15 @@ typedef struct hrt_flat_scene {
                               for the t < t_min self-hits of Q-2; the flattened BVH applies the same test to
                               accepted candidates so results do not depend on ITS topology.  NULL = use each
                               triangle's own padded box. */
+    const uint32_t* tri_ref_order; /* per triangle: (node << 1) | side, where `node` numbers the lowest
+                              BVHNodes of the reference's own tree for the mesh in depth-first order and
+                              `side` is 0 for that node's `left` child, 1 for `right` (bvh.cpp:20-36).  Once
+                              BVHNode::hit has accepted a hit with t < t_min every later BOX test fails
+                              (bvh.cpp:71 with t_max = rec.t), so among several such self-hits the reference
+                              keeps the one in the FIRST node its walk meets — except that the `right`
+                              triangle of that same node is still tested (no box in between, bvh.cpp:75) and
+                              wins if it is not farther.  The flattened traversal reproduces exactly that.
+                              NULL = every triangle its own node. */
     uint64_t n_nodes;      const hrt_bvh_node* nodes;
     uint64_t n_texels_u8;  const uint8_t* texels_u8;
     uint64_t n_texels_f32; const float* texels_f32;

@@ -1,0 +1,54 @@
+"""ctypes wrapper of tests/tools/libflatcpu.so (TEST TOOL ONLY: the product's device header compiled for the
+host, see flat_on_cpu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hobbyraytracer_amd import api
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+_lib = C.CDLL(os.path.join(_HERE, "libflatcpu.so"))
+_fp = C.POINTER(C.c_float)
+_lib.flatcpu_create.argtypes = [C.POINTER(api.FlatScene)]
+_lib.flatcpu_create.restype = C.c_void_p
+_lib.flatcpu_destroy.argtypes = [C.c_void_p]
+_lib.flatcpu_destroy.restype = None
+_lib.flatcpu_closest_hit.argtypes = [C.c_void_p, C.POINTER(api.Params), C.c_int64, _fp, _fp, C.c_float, C.c_float, C.c_uint32, C.POINTER(api.Hit)]
+_lib.flatcpu_closest_hit.restype = None
+_lib.flatcpu_render_tile.argtypes = [C.c_void_p, C.POINTER(api.Camera), C.POINTER(api.Params), api.Rect, _fp, C.POINTER(api.Stats)]
+_lib.flatcpu_render_tile.restype = None
+
+
+class FlatCpu:
+    def __init__(self, flat_ptr):
+        self._keep = flat_ptr
+        self._h = _lib.flatcpu_create(flat_ptr)
+
+    def close(self):
+        if self._h:
+            _lib.flatcpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def closest_hit(self, params, origins, dirs, t_min=0.001, t_max=float("inf"), pixel0=0):
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        out = np.zeros(o.shape[0], dtype=api.HIT_DTYPE)
+        _lib.flatcpu_closest_hit(self._h, C.byref(params), o.shape[0], o.ctypes.data_as(_fp), d.ctypes.data_as(_fp), t_min, t_max,
+                                 pixel0, out.ctypes.data_as(C.POINTER(api.Hit)))
+        return out
+
+    def render_tile(self, cam, params, rect=None):
+        if rect is None:
+            rect = api.Rect(0, 0, params.width, params.height)
+        elif not isinstance(rect, api.Rect):
+            rect = api.Rect(*rect)
+        out = np.empty((rect.h, rect.w, 3), dtype=np.float32)
+        st = api.Stats()
+        _lib.flatcpu_render_tile(self._h, C.byref(cam), C.byref(params), rect, out.ctypes.data_as(_fp), C.byref(st))
+        return out, st
