@@ -77,7 +77,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from hobbyraytracer_amd import api
+    from hobbyraytracer_amd import api, tiles
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,30 +106,18 @@ def main():
     dev = api.DeviceScene(hs.flat_ptr, local_rank)
 
     R = args.rows_per_block
-    my_rows = api.stripe_rows(H, R, rank, world)
-    rows_per_rank = [api.stripe_rows(H, R, r, world) for r in range(world)]
-    max_rows = max(rows_per_rank)
-    tile = torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda")
-    gathered = torch.zeros((world, max_rows, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
-    # permutation: film row -> (rank, local row) flattened index into `gathered`
-    perm = np.zeros(H, dtype=np.int64)
-    for r in range(world):
-        idx = api.stripe_row_indices(H, R, r, world)
-        perm[idx] = r * max_rows + np.arange(len(idx))
-    perm_t = torch.from_numpy(perm).cuda()
+    layout = tiles.StripeLayout(H, W, R, world)
+    my_rows = layout.rows[rank]
+    tile = torch.zeros((layout.max_rows, W, 3), dtype=torch.float32, device="cuda")
+    gathered = torch.zeros((world * layout.max_rows, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
     film_lin = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     film_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(p):
         dev.render_stripes_device(cam, p, R, rank, world, tile.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, tile)
-            src = gathered.view(world * max_rows, W, 3)
-        else:
-            src = tile
+        tiles.gather_film(tile, layout, dist, out=film_lin, gathered=gathered)   # RCCL all_gather when world > 1
         if rank == 0:
-            torch.index_select(src, 0, perm_t, out=film_lin)
             dev.resolve_u8_device(film_lin.data_ptr(), W * H, film_u8.data_ptr(), stream)
 
     def sync():

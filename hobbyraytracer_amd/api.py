@@ -218,6 +218,7 @@ class HostScene:
     """Scene::loadScene + flatten (scene.cpp:127-379)."""
 
     def __init__(self, yaml_path, asset_dir=None):
+        self._h = None
         h = _vp()
         _check_host(_host.hrt_host_load_yaml(os.fsencode(yaml_path), os.fsencode(asset_dir) if asset_dir else None, C.byref(h)))
         self._h = h
@@ -323,6 +324,7 @@ class DeviceScene:
     """hrt_scene: the flat scene resident on one GPU."""
 
     def __init__(self, flat, device=0):
+        self._h = None
         h = _vp()
         flat_ptr = flat if isinstance(flat, C.POINTER(FlatScene)) else C.pointer(flat)
         _check(_hip.hrt_scene_create(flat_ptr, device, C.byref(h)))

@@ -22,11 +22,18 @@ def built():
 
 @pytest.fixture(scope="session")
 def assets(built, tmp_path_factory):
-    """Procedural stand-ins for teapot.obj / old_hall_4k.hdr (small env map for tests)."""
+    """Procedural stand-ins for teapot.obj / marble_bust_01.obj / old_hall_4k.hdr (small ones for tests)."""
     from hobbyraytracer_amd import api
     d = tmp_path_factory.mktemp("assets")
     api.write_teapot_obj(str(d / "teapot.obj"), 1.0)
     api.write_hall_hdr(str(d / "old_hall_4k.hdr"), 512, 256)
+    api.write_bust_obj(str(d / "marble_bust_01.obj"), 0.25)   # ~6k triangles: the CPU tests stay fast
+    import numpy as np
+    img = np.zeros((32, 64, 3), np.uint8)
+    img[:, ::8] = [255, 40, 40]
+    img[:, 1::8] = [255, 40, 40]
+    img[::4] = [40, 40, 255]
+    api.write_image(str(d / "stripes.png"), img)               # image texture of material_zoo.yaml
     return str(d)
 
 

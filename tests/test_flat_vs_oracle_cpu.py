@@ -1,0 +1,158 @@
+"""CPU-only checks of everything about the flattened path that does not need a GPU to be wrong: the BVH the
+host builder emits, and the product's device header (csrc/hrt_device.h) compiled for the HOST by the test
+tool tests/tools/flat_on_cpu.cpp, against the oracle.  Bit equality is expected (same IEEE operations, both
+built with -ffp-contract=off).  The same comparisons run on the real kernels in tests/test_gpu_*.py."""
+import numpy as np
+import pytest
+
+SCENES = {  # name -> (W, H, spp)
+    "teapot_scene.yaml": (48, 48, 6),
+    "shiny_teapot.yaml": (64, 36, 6),
+    "cornell_box.yaml": (48, 48, 6),
+    "bust_scene.yaml": (40, 40, 4),
+    "material_zoo.yaml": (56, 56, 6),
+}
+
+
+@pytest.fixture(scope="module")
+def tools(built):
+    from oracle import oracle_py as orc
+    from tests.tools.flatcpu_py import FlatCpu
+    return orc, FlatCpu
+
+
+def _walk_bvh(flat, mesh_index):
+    m = flat.meshes[mesh_index]
+    nodes = [flat.nodes[m.node_first + i] for i in range(m.node_count)]
+    return m, nodes
+
+
+@pytest.mark.parametrize("scene", ["teapot_scene.yaml", "bust_scene.yaml"])
+def test_bvh_structure(built, assets, scenes_dir, scene):
+    """Every triangle in exactly one leaf; every child box contains the padded ITriangle boxes
+    (triangle.cpp:133-151) of the triangles below it; depth within the kernel's stack (32)."""
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
+    flat = hs.flat
+    m, nodes = _walk_bvh(flat, 0)
+    pos, _, _ = hs.mesh_arrays(0)
+    tmin = pos.min(1) - np.float32(0.0001)
+    tmax = pos.max(1) + np.float32(0.0001)
+    seen = np.zeros(m.tri_count, dtype=int)
+    max_depth = 0
+
+    def rec(ref, depth):
+        nonlocal max_depth
+        if ref < 0:
+            enc = (~ref) & 0xFFFFFFFF
+            first, count = enc >> 3, (enc & 7) + 1
+            seen[first:first + count] += 1
+            return tmin[first:first + count].min(0), tmax[first:first + count].max(0)
+        max_depth = max(max_depth, depth)
+        n = nodes[ref]
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        for c, (bmin, bmax, child) in enumerate((((n.c0_min_x, n.c0_min_y, n.c0_min_z), (n.c0_max_x, n.c0_max_y, n.c0_max_z), n.child0),
+                                                 ((n.c1_min_x, n.c1_min_y, n.c1_min_z), (n.c1_max_x, n.c1_max_y, n.c1_max_z), n.child1))):
+            if bmin[0] > bmax[0]:
+                continue  # empty slot
+            a, b = rec(child, depth + 1)
+            assert (np.array(bmin) <= a).all() and (np.array(bmax) >= b).all(), "child box must contain its triangles"
+            assert (a - np.array(bmin)).max() < 1e-3 and (np.array(bmax) - b).max() < 1e-3, "boxes stay tight"
+            lo, hi = np.minimum(lo, a), np.maximum(hi, b)
+        return lo, hi
+
+    import sys
+    sys.setrecursionlimit(10000)
+    rec(0, 1)
+    assert (seen == 1).all()
+    assert max_depth == hs.bvh_depth(0) <= 32
+    # reference leaf boxes / order codes: every triangle's acceptance box contains its own padded box
+    box = np.ctypeslib.as_array(flat.tri_box, shape=(flat.n_tris * 6,)).reshape(-1, 6)[m.tri_first:m.tri_first + m.tri_count]
+    assert (box[:, :3] <= tmin).all() and (box[:, 3:] >= tmax).all()
+    order = np.ctypeslib.as_array(flat.tri_ref_order, shape=(flat.n_tris,))[m.tri_first:m.tri_first + m.tri_count]
+    codes, counts = np.unique(order >> 1, return_counts=True)
+    assert counts.max() <= 2 and len(np.unique(order)) == m.tri_count     # 1- or 2-object lowest nodes (bvh.cpp:20-36)
+
+
+def test_degenerate_meshes(built, tmp_path, tools):
+    """Single triangle (root leaf) and the two-triangle case: flattened result == oracle."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    base = """
+film:
+    width: 16
+    height: 16
+    samples: 2
+    output: o.png
+camera:
+    position: [0, 0, 3]
+    look_at: [0, 0, 0]
+    up: [0, 1, 0]
+    fov: 50
+    aperture: 0
+    focal_distance: 3
+    background: [0.4, 0.5, 0.6]
+materials:
+  - name: m
+    type: lambertian
+    albedo: [0.8, 0.3, 0.3]
+objects:
+  - type: mesh
+    path: t.obj
+    material: m
+"""
+    for faces in ("f 1 2 3\n", "f 1 2 3\nf 1 3 4\n"):
+        (tmp_path / "t.obj").write_text("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvn 0 0 1\n" + faces.replace(" 1 ", " 1//1 ").replace("f 1 ", "f 1//1 "))
+        (tmp_path / "s.yaml").write_text(base)
+        hs = api.HostScene(str(tmp_path / "s.yaml"), str(tmp_path))
+        p = api.default_params(16, 16, 2)
+        a, _ = FlatCpu(hs.flat_ptr).render_tile(hs.camera(), p)
+        b, _ = orc.World(hs.flat_ptr).render_tile(hs.camera(), p)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert (np.abs(b - np.array([0.4, 0.5, 0.6], np.float32)).max(2) > 1e-3).sum() > 20   # the mesh is visible
+
+
+@pytest.mark.parametrize("quirks", ["reference", "fixed"])
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_image_flat_equals_oracle(built, assets, scenes_dir, tools, scene, quirks):
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    W, H, spp = SCENES[scene]
+    hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
+    q = api.QUIRKS_REFERENCE if quirks == "reference" else api.QUIRKS_FIXED
+    p = api.default_params(W, H, spp, quirks=q, stats=True)
+    cam = hs.camera(W, H)
+    a, sa = FlatCpu(hs.flat_ptr).render_tile(cam, p)
+    b, sb = orc.World(hs.flat_ptr).render_tile(cam, p)
+    assert (sa.rays, sa.samples, sa.mesh_hits, sa.env_lookups) == (sb.rays, sb.samples, sb.mesh_hits, sb.env_lookups)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    if hs.flat.n_meshes:   # the SAH tree must not do more work than the reference's median-split tree
+        assert sa.box_tests < sb.box_tests and sa.tri_tests < sb.tri_tests
+
+
+def test_closest_hit_flat_equals_oracle_with_self_hits(built, assets, scenes_dir, tools):
+    """300k rays that start ON mesh triangles (Q-2 self-hit coin flips, several candidates per ray near
+    shared edges): the flattened traversal picks exactly the reference's winner."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/shiny_teapot.yaml", assets)
+    world, flat = orc.World(hs.flat_ptr), FlatCpu(hs.flat_ptr)
+    r = np.random.default_rng(21)
+    o0 = r.uniform([-3, -0.5, 2.5], [3, 3, 4], (300000, 3)).astype(np.float32)
+    d0 = (r.uniform([-1.4, 0.0, -0.9], [1.6, 1.5, 0.9], (300000, 3)) - o0).astype(np.float32)
+    pf = api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED)
+    first = world.closest_hit(pf, o0, d0)
+    on = first["tri"] >= 0
+    assert on.sum() > 100000
+    # graze along the surface so that neighbouring triangles are hit within t_min too
+    n = first["normal"][on] / np.linalg.norm(first["normal"][on], axis=1, keepdims=True)
+    tang = np.cross(n, r.normal(size=n.shape))
+    d = (tang + 0.02 * n * r.normal(size=(len(n), 1))).astype(np.float32)
+    o = first["p"][on]
+    p = api.default_params(8, 8, 1)
+    g, c = flat.closest_hit(p, o, d), world.closest_hit(p, o, d)
+    assert ((c["tri"] >= 0) & (c["t"] < 1e-3)).sum() > 20000
+    assert np.array_equal(g["prim"], c["prim"]) and np.array_equal(g["tri"], c["tri"])
+    hit = c["prim"] >= 0
+    for f in ("t", "p", "normal", "u", "v"):
+        assert np.array_equal(g[f][hit].view(np.uint32), c[f][hit].view(np.uint32)), f

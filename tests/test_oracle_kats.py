@@ -1,0 +1,131 @@
+"""Pins the CPU oracle (oracle/oracle.cpp) against every golden vector the reference holds for this path
+(SURVEY.md §4 / §8c): the six sphere-UV vectors of sphere.cpp:9-11, the ACES constants of film.cpp:40-46
+and the quantisation rule of film.cpp:27-29; plus the restated glm semantics (quaternion, distributions)
+and the published Philox4x32-10 known-answer vectors.  Everything else the oracle computes is "parity
+unpinned" (no reference output exists): see DESIGN.md."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def orc(built):
+    from oracle import oracle_py
+    return oracle_py
+
+
+# sphere.cpp:9-11:  <1 0 0> -> <0.50 0.50>   <-1 0 0> -> <0.00 0.50>   <0 1 0> -> <0.50 1.00>
+#                   <0 -1 0> -> <0.50 0.00>  <0 0 1> -> <0.25 0.50>    <0 0 -1> -> <0.75 0.50>
+SPHERE_UV_KATS = [((1, 0, 0), (0.50, 0.50)), ((-1, 0, 0), (0.00, 0.50)), ((0, 1, 0), (0.50, 1.00)),
+                  ((0, -1, 0), (0.50, 0.00)), ((0, 0, 1), (0.25, 0.50)), ((0, 0, -1), (0.75, 0.50))]
+
+
+@pytest.mark.parametrize("p,uv", SPHERE_UV_KATS)
+def test_sphere_uv_golden_vectors(orc, p, uv):
+    got = orc.sphere_uv(p)
+    if p == (-1, 0, 0):
+        # atan2(-0, -1) + pi is 0 or 2*pi depending on the sign of zero: u is 0.00 modulo 1
+        assert min(abs(got[0] - 0.0), abs(got[0] - 1.0)) < 1e-6
+    else:
+        assert abs(got[0] - uv[0]) < 1e-6
+    assert abs(got[1] - uv[1]) < 1e-6
+
+
+def test_tonemap_constants_and_quantisation(orc):
+    """film.cpp:40-46 (a=2.51 b=0.03 c=2.43 d=0.59 e=0.14), sqrt gamma, film.cpp:27-29 uint8(256*clamp(c,0,0.9999))."""
+    x = np.array([[0.0, 0.18, 1.0], [4.0, 0.5, 0.01]], dtype=np.float32)
+    a, b, c, d, e = 2.51, 0.03, 2.43, 0.59, 0.14
+    xd = x.astype(np.float64)
+    ref = np.sqrt(np.clip((xd * (a * xd + b)) / (xd * (c * xd + d) + e), 0, 1))
+    np.testing.assert_allclose(orc.tonemap(x), ref, rtol=2e-6, atol=1e-7)
+    # quantisation: linear 0 -> 0 ; tonemapped 1.0 -> 255 ; tonemapped 0.5 -> 128
+    assert orc.resolve_u8(np.zeros((1, 3), np.float32)).tolist() == [[0, 0, 0]]
+    assert orc.resolve_u8(np.full((1, 3), 1e6, np.float32)).tolist() == [[255, 255, 255]]
+    # find linear value whose tonemap is 0.5 (sqrt(aces)=0.5 -> aces=0.25)
+    lin = np.float32(0.0)
+    lo, hi = 0.0, 1.0
+    for _ in range(60):
+        mid = (lo + hi) / 2
+        v = np.sqrt((mid * (a * mid + b)) / (mid * (c * mid + d) + e))
+        lo, hi = (mid, hi) if v < 0.5 else (lo, mid)
+    lin = np.float32(hi * 1.0001)
+    assert orc.resolve_u8(np.full((1, 3), lin, np.float32))[0, 0] == 128
+    # NaN scrub (film.cpp:35-37)
+    assert orc.resolve_u8(np.array([[np.nan, 0.0, np.nan]], np.float32)).tolist() == [[0, 0, 0]]
+
+
+def test_philox_known_answers(orc):
+    """Random123 kat_vectors for philox4x32-10."""
+    def run(ctr, key):
+        c = np.array(ctr, dtype=np.uint32).view(np.float32)
+        k = np.array(key, dtype=np.uint32).view(np.float32)
+        return orc.math_probe(5, c, k).view(np.uint32).tolist()
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_quaternion_euler_180_about_y(orc):
+    """glm::quat(radians(0,180,0)) * (x,y,z) = (-x, y, -z) (teapot_scene.yaml:78)."""
+    v = np.array([0.3, -1.2, 2.5], np.float32)
+    out = orc.quat_rotate_euler_deg([0, 180, 0], v)
+    np.testing.assert_allclose(out, [-0.3, -1.2, -2.5], atol=2e-6)
+    # 90 degrees about x: (x,y,z) -> (x,-z,y)
+    np.testing.assert_allclose(orc.quat_rotate_euler_deg([90, 0, 0], v), [0.3, -2.5, -1.2], atol=2e-6)
+    # 90 degrees about z: (x,y,z) -> (-y,x,z)
+    np.testing.assert_allclose(orc.quat_rotate_euler_deg([0, 0, 90], v), [1.2, 0.3, 2.5], atol=2e-6)
+
+
+def test_spherical_rand_distribution(orc):
+    """glm::sphericalRand(1): unit length, zero mean, uniform z (restated semantics)."""
+    v = orc.spherical_rand(123, 400000).astype(np.float64)
+    np.testing.assert_allclose(np.linalg.norm(v, axis=1), 1.0, atol=5e-6)
+    assert np.abs(v.mean(0)).max() < 5e-3
+    hist, _ = np.histogram(v[:, 2], bins=20, range=(-1, 1))
+    assert np.abs(hist / hist.mean() - 1).max() < 0.03
+    np.testing.assert_allclose((v ** 2).mean(0), 1 / 3, atol=3e-3)
+
+
+def test_ball_rand_distribution(orc):
+    """glm::ballRand(1): inside the unit ball, radius CDF ~ r^3."""
+    v = orc.ball_rand(7, 300000).astype(np.float64)
+    r = np.linalg.norm(v, axis=1)
+    assert r.max() <= 1.0 + 1e-6
+    for q in (0.2, 0.5, 0.8):
+        assert abs((r < q).mean() - q ** 3) < 4e-3
+    assert np.abs(v.mean(0)).max() < 5e-3
+
+
+def test_furnace_estimator(built, tmp_path):
+    """White-furnace check of the restated estimator (main.cpp:38-79): a Lambertian sphere with albedo 1
+    under a constant background L converges to L in every pixel (no absorption, no emission)."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    y = tmp_path / "furnace.yaml"
+    y.write_text("""
+film:
+    width: 24
+    height: 24
+    samples: 64
+    output: f.png
+camera:
+    position: [0, 0, 4]
+    look_at: [0, 0, 0]
+    up: [0, 1, 0]
+    fov: 35
+    aperture: 0
+    focal_distance: 4
+    background: [0.7, 0.5, 0.3]
+materials:
+  - name: white
+    type: lambertian
+    albedo: [1, 1, 1]
+objects:
+  - type: sphere
+    center: [0, 0, 0]
+    radius: 1
+    material: white
+""")
+    hs = api.HostScene(str(y))
+    img, st = orc.World(hs.flat_ptr).render_tile(hs.camera(), api.default_params(24, 24, 64, quirks=api.QUIRKS_FIXED, max_depth=200))
+    np.testing.assert_allclose(img.reshape(-1, 3).mean(0), [0.7, 0.5, 0.3], rtol=2e-3)
+    assert np.abs(img - np.array([0.7, 0.5, 0.3], np.float32)).max() < 0.02
