@@ -627,6 +627,10 @@ struct ConstantMedium : Hittable {
         rec.normal = vec3(1, 0, 0);
         rec.frontFace = true;
         rec.matPtr = phaseFunction;
+        // constantMedium.cpp:30-36 leaves rec.u / rec.v untouched: in the reference they hold whatever the
+        // previous successful object of the world list wrote into HittableList::hit's tempRec (or garbage).
+        // Defined here as 0 (only a texture-valued Isotropic albedo could ever read them).
+        rec.u = 0.0f; rec.v = 0.0f;
         rec.tri = -1;
         return true;
     }
