@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--megakernel", action="store_true", help="time the persistent-lanes megakernel instead of the wavefront pipeline")
     args = ap.parse_args()
 
     import numpy as np
@@ -101,8 +102,8 @@ def main():
     W, H, spp = args.width, args.height, args.spp
     cam = hs.camera(W, H)
     quirks = api.QUIRKS_REFERENCE if args.quirks == "reference" else api.QUIRKS_FIXED
-    params = api.default_params(W, H, spp, quirks=quirks, seed=0)
-    params_stats = api.default_params(W, H, spp, quirks=quirks, seed=0, stats=True)
+    params = api.default_params(W, H, spp, quirks=quirks, seed=0, megakernel=args.megakernel, timing=True)
+    params_stats = api.default_params(W, H, spp, quirks=quirks, seed=0, stats=True, megakernel=args.megakernel)
     dev = api.DeviceScene(hs.flat_ptr, local_rank)
 
     R = args.rows_per_block
@@ -160,8 +161,20 @@ def main():
     if rank == 0:
         ms_per_step = seconds / args.steps * 1e3
         mrays = total_rays / seconds / 1e6
-        # roofline of the dominant kernel (k_pathtrace) on rank 0's device
-        achieved = alg_bytes_launch / (float(kern.item()) * 1e-3) / 1e9
+        # roofline of the dominant kernel on rank 0's device.
+        #   wavefront pipeline: k_wf_ext (BVH traversal): bytes = 32 B per box + 36 B per triangle it tested,
+        #   launches = its launches per frame (one per round per mesh), time = HIP events around each launch.
+        #   megakernel: k_pathtrace, all of SURVEY §8(d)'s bytes, one launch per frame.
+        frame_ms = float(kern.item())
+        if args.megakernel or st.traversal_launches == 0:
+            kname, k_launches = "k_pathtrace", 1
+            k_bytes, k_ms = float(alg_bytes_launch), frame_ms
+        else:
+            kname, k_launches = "k_wf_ext", st.traversal_launches / max(1, st.launches)
+            k_bytes = (32.0 * st_count.box_tests + 36.0 * st_count.tri_tests) / k_launches
+            k_ms = st.traversal_ms / st.traversal_launches
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        pipeline_gbps = alg_bytes_launch / (frame_ms * 1e-3) / 1e9
         result = {
             "metric": "Mrays/sec (path segments/s), teapot_scene.yaml 640x640 100spp",
             "value": round(mrays, 3),
@@ -176,14 +189,18 @@ def main():
             "dtype": "f32",
             "data": "synthetic (procedural teapot.obj ~6.2k tris + procedural 4096x2048 old_hall_4k.hdr stand-ins; seed 0)",
             "config": {"workload": f"{args.scene} {W}x{H} {spp}spp, quirks={args.quirks}, max_depth=50",
+                       "render_path": "megakernel k_pathtrace" if args.megakernel else "wavefront pipeline k_wf_gen/pre/ext/shade/reduce",
                        "parallelism": f"image row blocks of {R} rows interleaved over {world} GPU(s); RCCL all_gather of fp32 film tiles" if world > 1 else "single GPU",
                        "rays_per_step": total_rays / args.steps, "samples_per_step": total_samples / args.steps,
                        "msamples_per_s": round(total_samples / seconds / 1e6, 3),
                        "wall_clock_s_per_frame": round(seconds / args.steps, 6),
                        "reference_readme_wall_clock_s": 150.0},
-            "roofline": {"bound": "hbm", "kernel": "k_pathtrace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch, "kernel_ms_per_launch": round(float(kern.item()), 4),
+                         "algorithmic_bytes_per_launch": round(k_bytes, 1), "kernel_ms_per_launch": round(k_ms, 5),
+                         "launches_per_frame": k_launches, "kernel_ms_per_frame": round(k_ms * k_launches, 4),
+                         "frame_pipeline_ms": round(frame_ms, 4), "frame_algorithmic_bytes": alg_bytes_launch,
+                         "frame_algorithmic_gbps": round(pipeline_gbps, 2),
                          "box_tests_per_ray": round(st_count.box_tests / max(1, st_count.rays), 3),
                          "tri_tests_per_ray": round(st_count.tri_tests / max(1, st_count.rays), 3)},
         }

@@ -31,7 +31,7 @@ TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_ENV = range(4)
 MAX_XFORMS = 4
 Q1_ROTQ_NORMALIZE, Q2_TRI_NO_TMIN, Q3_TRI_NO_FACE, Q4_SHEAR_FROM_ORIGIN = 1, 2, 4, 8
 QUIRKS_REFERENCE, QUIRKS_FIXED = 0xF, 0x0
-FLAG_STATS = 1
+FLAG_STATS, FLAG_MEGAKERNEL, FLAG_TIMING = 1, 2, 4
 
 
 # ---------------------------------------------------------------- structs (hrt.h)
@@ -99,7 +99,8 @@ class Rect(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("mesh_hits", C.c_uint64), ("env_lookups", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64)]
+                ("mesh_hits", C.c_uint64), ("env_lookups", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64),
+                ("traversal_ms", C.c_double), ("traversal_launches", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -203,14 +204,14 @@ def _ptr(a, t=_fp):
 
 
 # ---------------------------------------------------------------- host side
-def default_params(width, height, samples, quirks=QUIRKS_REFERENCE, seed=0, max_depth=50, stats=False):
+def default_params(width, height, samples, quirks=QUIRKS_REFERENCE, seed=0, max_depth=50, stats=False, megakernel=False, timing=False):
     p = Params()
     _host.hrt_default_params(C.byref(p), width, height, samples)
     p.quirks = quirks
     p.seed_lo = seed & 0xFFFFFFFF
     p.seed_hi = (seed >> 32) & 0xFFFFFFFF
     p.max_depth = max_depth
-    p.flags = FLAG_STATS if stats else 0
+    p.flags = (FLAG_STATS if stats else 0) | (FLAG_MEGAKERNEL if megakernel else 0) | (FLAG_TIMING if timing else 0)
     return p
 
 

@@ -288,109 +288,167 @@ __device__ inline bool accept_box(float4 bmn, float4 bmx, vec3 o, vec3 d, float 
 }
 
 // ------------------------------------------------------------------ Mesh::hit -> BVHNode::hit (mesh.cpp:43-46, bvh.cpp:69-78)
-// Flattened 2-wide BVH, per-lane stack in LDS (stack[depth][thread]: lanes of a
-// wave hit distinct banks whatever their depths).  Returns the closest
-// accepted triangle in [.., t_max] or -1.
-template <bool STATS>
-__device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 o, vec3 d, float t_min, float t_max,
-                                   uint32_t quirks, int* stack /* + threadIdx.x */, float& t_out, DCounters& cnt) {
-    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
-    const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
-    const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
-    const TriRay tr = tri_ray_setup(o, d, quirks);
-    // culling-only constants (free to differ from the reference: see header)
-    const float idx = 1.0f / d.x, idy = 1.0f / d.y, idz = 1.0f / d.z;
-    const float ox = o.x * idx, oy = o.y * idy, oz = o.z * idz;
-    float closest = t_max;
-    int best = -1;
-    // Culling interval [t_lo, closest].  With Q-2 the reference accepts triangle hits at any t > 0 as long
-    // as the boxes of ITS tree pass [t_min, t_max]; those boxes are not the ones of this tree, so cull
-    // from 0 (every t > 0 candidate is then reached) and let accept_box apply the reference's own
-    // leaf-level box afterwards.
-    const float t_lo = (quirks & HRT_Q2_TRI_NO_TMIN) ? 0.0f : t_min;
+// Flattened 2-wide BVH walked by a RESUMABLE state machine: trav_step() advances one lane by one node or
+// one leaf, so the megakernel (bvh_traverse below) and the wavefront traversal kernel (which refills
+// finished lanes with new rays between steps) run the very same code.  Per-lane stack in LDS
+// (stack[depth][thread]: lanes of a wave hit distinct banks whatever their depths).
+struct MeshRay {          // a ray in mesh space plus its per-ray constants
+    vec3 o, d;
+    TriRay tr;            // exact-arithmetic constants of the triangle test
+    float idx, idy, idz;  // culling-only constants (free to differ from the reference: see header)
+    float ox, oy, oz;
+};
+__device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks) {
+    MeshRay r;
+    r.o = o; r.d = d;
+    r.tr = tri_ray_setup(o, d, quirks);
+    r.idx = 1.0f / d.x; r.idy = 1.0f / d.y; r.idz = 1.0f / d.z;
+    r.ox = o.x * r.idx; r.oy = o.y * r.idy; r.oz = o.z * r.idz;
+    return r;
+}
+#define HRT_TRAV_DONE 0x7fffffff
+struct TravState {
+    float closest;        // t_max, shrinking
+    int best;             // closest accepted triangle so far (mesh-local index) or -1
     // Self-hits (Q-2): a candidate with t < t_min.  In the reference, once one is accepted every later
     // BOX test fails (bvh.cpp:71 gets t_max = rec.t < t_min), so the one in the FIRST lowest-level node of
     // its own tree's depth-first walk wins, whatever its distance (the two triangles of that one node are
     // both tested, bvh.cpp:74-75).  Here: after the first self-hit the interval shrinks to
     // [0, t_min+] -- only boxes that close to the origin can hold another self-hit -- and candidates are
     // ranked by hrt_flat_scene::tri_ref_order.
-    bool selfhit = false;
-    uint32_t self_order = 0xffffffffu;
-    int self_tri = -1;
-    float self_t = 0.0f;
-    int sp = 0;
-    int cur = 0;  // root
-    const int SENTINEL = 0x7fffffff;
-    if (mesh.node_count == 0) cur = SENTINEL;
-    while (cur != SENTINEL) {
-        if (cur >= 0) {
-            const float4 n0 = nodes[4 * cur + 0];
-            const float4 n1 = nodes[4 * cur + 1];
-            const float4 n2 = nodes[4 * cur + 2];
-            const float4 n3 = nodes[4 * cur + 3];
-            if (STATS) cnt.box_tests += 2;
-            // child 0
-            float a0 = fmaf(n0.x, idx, -ox), a1 = fmaf(n0.y, idx, -ox);
-            float b0 = fmaf(n0.z, idy, -oy), b1 = fmaf(n0.w, idy, -oy);
-            float c0 = fmaf(n2.x, idz, -oz), c1 = fmaf(n2.y, idz, -oz);
-            float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_lo));
-            float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), closest));
-            // child 1
-            float e0 = fmaf(n1.x, idx, -ox), e1 = fmaf(n1.y, idx, -ox);
-            float f0 = fmaf(n1.z, idy, -oy), f1 = fmaf(n1.w, idy, -oy);
-            float g0 = fmaf(n2.z, idz, -oz), g1 = fmaf(n2.w, idz, -oz);
-            float tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_lo));
-            float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), closest));
-            const bool h0 = tn0 <= tf0;
-            const bool h1 = tn1 <= tf1;
-            const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                const int nearc = swap ? ch1 : ch0, farc = swap ? ch0 : ch1;
-                stack[sp * HRT_BLOCK] = farc; ++sp;
-                cur = nearc;
-            } else if (h0) cur = ch0;
-            else if (h1) cur = ch1;
-            else if (sp > 0) { --sp; cur = stack[sp * HRT_BLOCK]; }
-            else cur = SENTINEL;
-        } else {
-            const uint32_t enc = (uint32_t)(~cur);
-            const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t ti = first + k;
-                const float4 q0 = tpos[3 * ti + 0], q1 = tpos[3 * ti + 1], q2 = tpos[3 * ti + 2];
-                if (STATS) cnt.tri_tests += 1;
-                TriEval ev;
-                if (!tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;
-                // triangle.cpp:106-109
-                if (ev.det < 0 && (ev.tScaled >= 0 || ev.tScaled < closest * ev.det)) continue;
-                else if (ev.det > 0 && (ev.tScaled <= 0 || ev.tScaled > closest * ev.det)) continue;
-                const float invDet = 1 / ev.det;
-                const float t = ev.tScaled * invDet;
-                if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
-                const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
-                if (!accept_box(bmn, bmx, o, d, t_min, closest)) continue;
-                if (t < t_min) {
-                    const uint32_t ord = (uint32_t)__float_as_int(bmn.w);
-                    bool take;
-                    if (!selfhit) take = true;
-                    else if ((ord >> 1) != (self_order >> 1)) take = (ord >> 1) < (self_order >> 1);
-                    else if (ord & 1u) take = !(t > self_t);   // this is `right`, the kept one is `left`: bvh.cpp:75
-                    else take = self_t > t;                     // this is `left`: `right` survives only if not farther
-                    if (take) { self_order = ord; self_tri = (int)ti; self_t = t; }
-                    if (!selfhit) { selfhit = true; closest = t_min * 1.0001f; }
-                } else if (!selfhit) {
-                    closest = t;
-                    best = (int)ti;
-                }
-            }
-            if (sp > 0) { --sp; cur = stack[sp * HRT_BLOCK]; }
-            else cur = SENTINEL;
+    bool selfhit;
+    uint32_t self_order;
+    int self_tri;
+    float self_t;
+    int sp;
+    int cur;              // node index (>= 0), leaf code (< 0) or HRT_TRAV_DONE
+};
+__device__ inline void trav_init(TravState& ts, const hrt_mesh& mesh, float t_max) {
+    ts.closest = t_max; ts.best = -1;
+    ts.selfhit = false; ts.self_order = 0xffffffffu; ts.self_tri = -1; ts.self_t = 0.0f;
+    ts.sp = 0;
+    ts.cur = mesh.node_count == 0 ? HRT_TRAV_DONE : 0;
+}
+// Culling interval [t_lo, closest].  With Q-2 the reference accepts triangle hits at any t > 0 as long as
+// the boxes of ITS tree pass [t_min, t_max]; those boxes are not the ones of this tree, so cull from 0
+// (every t > 0 candidate is then reached) and let accept_box apply the reference's own leaf-level box.
+// ts.cur encodings: inner node index in [0, HRT_TRAV_DONE), leaf code < 0, HRT_TRAV_DONE = finished.
+__device__ inline bool trav_at_inner(const TravState& ts) { return (unsigned)ts.cur < (unsigned)HRT_TRAV_DONE; }
+__device__ inline bool trav_at_leaf(const TravState& ts) { return ts.cur < 0; }
+__device__ inline float trav_t_lo(float t_min, uint32_t quirks) { return (quirks & HRT_Q2_TRI_NO_TMIN) ? 0.0f : t_min; }
+
+// Slab test of BOTH child boxes of one 64-byte node against [t_lo, t_hi] (culling only).
+__device__ inline void node_test(const float4& n0, const float4& n1, const float4& n2, const MeshRay& r, float t_lo, float t_hi,
+                                 float& tn0, bool& h0, float& tn1, bool& h1) {
+    float a0 = fmaf(n0.x, r.idx, -r.ox), a1 = fmaf(n0.y, r.idx, -r.ox);
+    float b0 = fmaf(n0.z, r.idy, -r.oy), b1 = fmaf(n0.w, r.idy, -r.oy);
+    float c0 = fmaf(n2.x, r.idz, -r.oz), c1 = fmaf(n2.y, r.idz, -r.oz);
+    tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_lo));
+    float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), t_hi));
+    float e0 = fmaf(n1.x, r.idx, -r.ox), e1 = fmaf(n1.y, r.idx, -r.ox);
+    float f0 = fmaf(n1.z, r.idy, -r.oy), f1 = fmaf(n1.w, r.idy, -r.oy);
+    float g0 = fmaf(n2.z, r.idz, -r.oz), g1 = fmaf(n2.w, r.idz, -r.oz);
+    tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_lo));
+    float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), t_hi));
+    h0 = tn0 <= tf0;
+    h1 = tn1 <= tf1;
+}
+// The wavefront pipeline's root filter: would the first traversal step find any child of the root?
+// (Exactly the test trav_inner performs on node 0, so filtering changes no result.)
+__device__ inline bool root_may_hit(const DScene& sc, const hrt_mesh& mesh, const MeshRay& r, float t_lo, float t_hi) {
+    if (mesh.node_count == 0) return false;
+    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    float tn0, tn1; bool h0, h1;
+    node_test(nodes[0], nodes[1], nodes[2], r, t_lo, t_hi, tn0, h0, tn1, h1);
+    return h0 || h1;
+}
+
+// One inner-node step: tests both children of node ts.cur, descends / pushes / pops.
+template <bool STATS>
+__device__ inline void trav_inner(const float4* __restrict__ nodes, const MeshRay& r, TravState& ts, float t_lo, int* stack,
+                                  DCounters& cnt) {
+    const int cur = ts.cur;
+    const float4 n0 = nodes[4 * cur + 0];
+    const float4 n1 = nodes[4 * cur + 1];
+    const float4 n2 = nodes[4 * cur + 2];
+    const float4 n3 = nodes[4 * cur + 3];
+    if (STATS) cnt.box_tests += 2;
+    float tn0, tn1; bool h0, h1;
+    node_test(n0, n1, n2, r, t_lo, ts.closest, tn0, h0, tn1, h1);
+    const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
+    if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        const int nearc = swap ? ch1 : ch0, farc = swap ? ch0 : ch1;
+        stack[ts.sp * HRT_BLOCK] = farc; ++ts.sp;
+        ts.cur = nearc;
+    } else if (h0) ts.cur = ch0;
+    else if (h1) ts.cur = ch1;
+    else if (ts.sp > 0) { --ts.sp; ts.cur = stack[ts.sp * HRT_BLOCK]; }
+    else ts.cur = HRT_TRAV_DONE;
+}
+
+// One leaf: every triangle of leaf code ts.cur through the exact ITriangle test, then pop.
+template <bool STATS>
+__device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* __restrict__ tbox, const MeshRay& r, TravState& ts,
+                                 float t_min, uint32_t quirks, int* stack, DCounters& cnt) {
+    const uint32_t enc = (uint32_t)(~ts.cur);
+    const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t ti = first + k;
+        const float4 q0 = tpos[3 * ti + 0], q1 = tpos[3 * ti + 1], q2 = tpos[3 * ti + 2];
+        if (STATS) cnt.tri_tests += 1;
+        TriEval ev;
+        if (!tri_eval(r.tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;
+        // triangle.cpp:106-109
+        if (ev.det < 0 && (ev.tScaled >= 0 || ev.tScaled < ts.closest * ev.det)) continue;
+        else if (ev.det > 0 && (ev.tScaled <= 0 || ev.tScaled > ts.closest * ev.det)) continue;
+        const float invDet = 1 / ev.det;
+        const float t = ev.tScaled * invDet;
+        if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
+        const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
+        if (!accept_box(bmn, bmx, r.o, r.d, t_min, ts.closest)) continue;
+        if (t < t_min) {
+            const uint32_t ord = (uint32_t)__float_as_int(bmn.w);
+            bool take;
+            if (!ts.selfhit) take = true;
+            else if ((ord >> 1) != (ts.self_order >> 1)) take = (ord >> 1) < (ts.self_order >> 1);
+            else if (ord & 1u) take = !(t > ts.self_t);   // this is `right`, the kept one is `left`: bvh.cpp:75
+            else take = ts.self_t > t;                     // this is `left`: `right` survives only if not farther
+            if (take) { ts.self_order = ord; ts.self_tri = (int)ti; ts.self_t = t; }
+            if (!ts.selfhit) { ts.selfhit = true; ts.closest = t_min * 1.0001f; }
+        } else if (!ts.selfhit) {
+            ts.closest = t;
+            ts.best = (int)ti;
         }
     }
-    if (selfhit) { t_out = self_t; return self_tri; }
-    t_out = closest;
-    return best;
+    if (ts.sp > 0) { --ts.sp; ts.cur = stack[ts.sp * HRT_BLOCK]; }
+    else ts.cur = HRT_TRAV_DONE;
+}
+// Result of a finished traversal: winning triangle (or -1) and its t.
+__device__ inline int trav_result(const TravState& ts, float& t_out) {
+    if (ts.selfhit) { t_out = ts.self_t; return ts.self_tri; }
+    t_out = ts.closest;
+    return ts.best;
+}
+
+// Whole traversal for one lane (megakernel / test kernels).
+template <bool STATS>
+__device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 o, vec3 d, float t_min, float t_max,
+                                   uint32_t quirks, int* stack /* + threadIdx.x */, float& t_out, DCounters& cnt) {
+    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
+    const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
+    const MeshRay r = mesh_ray_setup(o, d, quirks);
+    const float t_lo = trav_t_lo(t_min, quirks);
+    TravState ts;
+    trav_init(ts, mesh, t_max);
+    // while-while: lanes that reach a leaf wait at the end of the inner loop, so the (expensive) leaf code
+    // runs with many lanes at once instead of once per node step for the few lanes that happen to be at a leaf
+    while (ts.cur != HRT_TRAV_DONE) {
+        while (trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
+        if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, t_min, quirks, stack, cnt);
+    }
+    return trav_result(ts, t_out);
 }
 
 // triangle.cpp:111-128 for the winning triangle
@@ -447,6 +505,26 @@ __device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_m
         if (hit) { closest = t; wh.prim = i; wh.sub = sub; wh.t = t; }
     }
     return wh;
+}
+
+// The analytic (non-mesh) part of the world list walk for prims [p0, p1): the body of the loop at
+// hittableList.cpp:12-19 with closest-so-far carried in and out.  Mesh prims are skipped (the wavefront
+// pipeline handles them between two calls of this function, in list order).
+__device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o, vec3 d, float t_min, uint32_t quirks,
+                                       const rng_ctx& ctx, float& closest, int& prim, int& sub) {
+    for (int i = p0; i < p1; ++i) {
+        const hrt_prim& pr = sc.prims[i];
+        const int kind = pr.kind;
+        if (kind == HRT_PRIM_MESH) continue;
+        vec3 lo = o, ld = d;
+        for (int k = 0; k < pr.n_xforms; ++k) xf_apply(pr.xf[k], lo, ld, quirks);
+        float t; int sb = -1; bool hit;
+        if (kind == HRT_PRIM_SPHERE) hit = sphere_hit(pr.p, lo, ld, t_min, closest, t);
+        else if (kind == HRT_PRIM_BOX) hit = box_hit(pr.p, lo, ld, t_min, closest, t, sb);
+        else if (kind == HRT_PRIM_MEDIUM) hit = medium_hit(pr, (uint32_t)i, lo, ld, t_min, closest, ctx, t);
+        else hit = rect_hit(rect_axis(kind), pr.p, lo, ld, t_min, closest, t);
+        if (hit) { closest = t; prim = i; sub = sb; }
+    }
 }
 
 // Rebuilds the winner's hitRecord exactly as the reference's call chain does.
@@ -612,14 +690,12 @@ __device__ inline void path_begin(const hrt_camera& cam, const hrt_params& pr, i
     ps.atten = vec3(1.0f); ps.result = vec3(0.0f); ps.bounce = 0;
 }
 
-// One iteration of the loop at main.cpp:43-76.  Returns true when the path has ended
+// The part of one iteration of main.cpp:43-76 that follows world->hit: background on a miss
+// (main.cpp:47-59), else emitted + scatter (main.cpp:62-75).  Returns true when the path has ended
 // (miss, emitter / absorbed, or MAX_DEPTH segments traced).
 template <bool STATS>
-__device__ inline bool path_segment(const DScene& sc, const hrt_params& pr, rng_ctx& ctx, PathState& ps, int* stack,
-                                    PathCounters& pc) {
-    ctx.bounce = (uint32_t)ps.bounce;
-    pc.rays++;
-    const WorldHit wh = world_hit<STATS>(sc, ps.o, ps.d, pr.t_min, __builtin_huge_valf(), pr.quirks, ctx, stack, pc.bvh);
+__device__ inline bool path_shade(const DScene& sc, const hrt_params& pr, const rng_ctx& ctx, PathState& ps, const WorldHit& wh,
+                                  PathCounters& pc) {
     if (wh.prim < 0) {
         if (STATS && sc.texs[sc.background_tex].kind == HRT_TEX_ENV) pc.env_lookups++;
         ps.result += ps.atten * background_value(sc, ps.d);
@@ -636,6 +712,16 @@ __device__ inline bool path_segment(const DScene& sc, const hrt_params& pr, rng_
     ps.o = so; ps.d = sd;
     ps.bounce++;
     return ps.bounce >= pr.max_depth;
+}
+
+// One iteration of the loop at main.cpp:43-76.  Returns true when the path has ended.
+template <bool STATS>
+__device__ inline bool path_segment(const DScene& sc, const hrt_params& pr, rng_ctx& ctx, PathState& ps, int* stack,
+                                    PathCounters& pc) {
+    ctx.bounce = (uint32_t)ps.bounce;
+    pc.rays++;
+    const WorldHit wh = world_hit<STATS>(sc, ps.o, ps.d, pr.t_min, __builtin_huge_valf(), pr.quirks, ctx, stack, pc.bvh);
+    return path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
 }
 
 // film.cpp:32-52 + 25-30

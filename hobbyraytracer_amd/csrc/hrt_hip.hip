@@ -14,7 +14,9 @@
 //   k_math_probe        the shared math kernels, for CPU==GPU bit tests.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -186,6 +188,283 @@ __global__ void k_math_probe(int op, long long n, const float* __restrict__ in, 
     }
 }
 
+// ===================================================================== wavefront pipeline (default path)
+// The same render() as k_pathtrace, organised for wave density instead of per-lane persistence:
+//   * every (pixel, sample) of the batch owns a SLOT of path state in HBM (the 288 GB make a whole
+//     640x640x100 frame = 41 M slots = 6.7 GB affordable), so samples run in parallel;
+//   * one ROUND = one path segment of every live slot: k_wf_pre (analytic prims in list order, mesh-space
+//     ray setup, root-box filter) -> k_wf_ext (persistent BVH traversal of the surviving rays only) ->
+//     k_wf_shade (remaining prims, hitRecord, scatter, compaction of the survivors);
+//   * k_wf_reduce adds each pixel's samples in sample order (main.cpp:118-126), so the fp32 sum has the
+//     reference's order although the samples were traced concurrently.
+// Lists are TASK-SEGMENTED: slots are cut into tasks of `T` consecutive slots; a task is always handled
+// by one wave, which compacts its live slots / queued rays in place inside the task's segment using
+// ballots only.  No list append ever touches a global atomic (a single address sustains only ~88 atomics
+// per microsecond on this chip: MI355X_MICROARCH.md "dequeue"); the traversal kernel pulls whole tasks,
+// one atomic per task.  Everything is driven by DEVICE-side counts: the host enqueues max_depth rounds
+// back to back with no synchronisation.
+struct WfBuf {
+    float4 *A, *B, *C, *D;       // A = o.xyz, closest t | B = d.xyz, - | C = attenuation | D = result
+    int2* H;                     // hit prim, sub (triangle / box side)
+    float4 *E0, *E1, *E2, *E3;   // traversal records (at the queue position): o' tmax | d' slot | sX sY sZ kZ | 1/d'
+    float4* rad;                 // radiance of the finished path of each slot
+    unsigned* list;              // live slots of task k at [k*T, k*T + live[k])  (implicit identity in round 0)
+    unsigned* live;              // per task: live slots
+    unsigned* qn;                // per task: rays queued for the current mesh at [k*T, k*T + qn[k]) of E0..E3
+    unsigned* heads;             // per (round, mesh): next task for k_wf_ext
+    unsigned T, n_tasks;
+};
+
+__device__ inline void slot_pixel(const RenderMap& map, unsigned lp, int& px, int& py) {
+    const int lx = (int)(lp % (unsigned)map.rw), ly = (int)(lp / (unsigned)map.rw);
+    if (map.mode == 0) { px = map.x0 + lx; py = map.y0 + ly; }
+    else { const int b = ly / map.R; px = lx; py = (b * map.G + map.rank) * map.R + (ly - b * map.R); }
+}
+__device__ inline rng_ctx slot_ctx(const hrt_params& pr, const RenderMap& map, unsigned slot, unsigned n_local, int s0, int bounce) {
+    int px, py;
+    slot_pixel(map, slot % n_local, px, py);
+    rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi;
+    ctx.pixel = (uint32_t)(py * pr.width + px); ctx.sample = (uint32_t)(s0 + (int)(slot / n_local)); ctx.bounce = (uint32_t)bounce;
+    return ctx;
+}
+
+__global__ __launch_bounds__(256) void k_wf_gen(hrt_camera cam, hrt_params pr, RenderMap map, unsigned n_local, int s0,
+                                                unsigned n_slots, WfBuf w) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned k = gid; k < w.n_tasks; k += stride) {
+        const unsigned first = k * w.T;
+        w.live[k] = first < n_slots ? min(w.T, n_slots - first) : 0u;
+    }
+    for (unsigned slot = gid; slot < n_slots; slot += stride) {
+        int px, py;
+        slot_pixel(map, slot % n_local, px, py);
+        rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi;
+        ctx.pixel = (uint32_t)(py * pr.width + px); ctx.sample = (uint32_t)(s0 + (int)(slot / n_local)); ctx.bounce = 0;
+        PathState ps;
+        path_begin(cam, pr, px, py, ctx, ps);
+        w.A[slot] = make_float4(ps.o.x, ps.o.y, ps.o.z, __builtin_huge_valf());
+        w.B[slot] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f);
+        w.C[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        w.D[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        w.H[slot] = make_int2(-1, -1);
+    }
+}
+
+// Analytic prims [p0, p1) in list order, then the mesh-space ray of prim `mesh_prim` + root filter + enqueue.
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, RenderMap map, unsigned n_local, int s0, int round,
+                                                int p0, int p1, int mesh_prim, WfBuf w, DeviceCounters* counters) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned n_culled = 0, n_seg = 0;
+    const hrt_prim& mp = sc.prims[mesh_prim];
+    const hrt_mesh mesh = sc.meshes[mp.mesh];
+    const float t_lo = trav_t_lo(pr.t_min, pr.quirks);
+    for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
+        const unsigned base = task * w.T;
+        const unsigned n = w.live[task];
+        unsigned qpos = base;
+        for (unsigned j0 = 0; j0 < n; j0 += 64) {
+            const unsigned j = j0 + lane;
+            bool enqueue = false;
+            unsigned slot = 0;
+            MeshRay mr;
+            float closest = 0.0f;
+            if (j < n) {
+                slot = round == 0 ? base + j : w.list[base + j];
+                const float4 a = w.A[slot], b = w.B[slot];
+                const vec3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
+                closest = a.w;
+                int2 h = w.H[slot];
+                const int prim0 = h.x;
+                if (p0 == 0) n_seg++;
+                if (p1 > p0) {
+                    const rng_ctx ctx = slot_ctx(pr, map, slot, n_local, s0, round);
+                    prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, h.x, h.y);
+                    if (h.x != prim0) { ((float*)&w.A[slot])[3] = closest; w.H[slot] = h; }
+                }
+                vec3 lo = o, ld = d;
+                for (int k = 0; k < mp.n_xforms; ++k) xf_apply(mp.xf[k], lo, ld, pr.quirks);
+                mr = mesh_ray_setup(lo, ld, pr.quirks);
+                enqueue = root_may_hit(sc, mesh, mr, t_lo, closest);
+                if (STATS && !enqueue && mesh.node_count) n_culled++;
+            }
+            const unsigned long long m = __ballot(enqueue);
+            if (enqueue) {
+                const unsigned q = qpos + (unsigned)__popcll(m & lt);
+                w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, closest);
+                w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(slot));
+                w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
+                w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, 0.0f);
+            }
+            qpos += (unsigned)__popcll(m);
+        }
+        if (lane == 0) w.qn[task] = qpos - base;
+    }
+    const unsigned seg = wave_sum(n_seg);
+    if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
+    if (STATS) {
+        const unsigned c = wave_sum(n_culled);
+        if (lane == 0 && c) atomicAdd(&counters->box_tests, 2ull * c);   // the root's two boxes were tested
+    }
+}
+
+// Persistent BVH traversal of the queued rays of one mesh prim.  A wave pulls whole tasks (one atomic
+// each) and hands their rays to its lanes as they fall idle (ballot + prefix count, no atomics).
+template <bool STATS>
+__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, WfBuf w, unsigned* head,
+                                                      DeviceCounters* counters) {
+    __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const hrt_mesh mesh = sc.meshes[sc.prims[mesh_prim].mesh];
+    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
+    const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
+    const float t_lo = trav_t_lo(pr.t_min, pr.quirks);
+    bool has = false;
+    unsigned cur_pos = 0, cur_end = 0;   // wave-uniform: unread rays of the wave's current task
+    bool wave_done = false;              // wave-uniform: no task left
+    MeshRay r;
+    TravState ts;
+    ts.cur = HRT_TRAV_DONE;
+    unsigned slot = 0;
+    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+    for (;;) {
+        const unsigned long long need = __ballot(!has);
+        if (need && !wave_done) {
+            while (cur_pos >= cur_end && !wave_done) {
+                unsigned t = 0;
+                if (lane == 0) t = atomicAdd(head, 1u);
+                t = __shfl(t, 0, 64);
+                if (t >= w.n_tasks) wave_done = true;
+                else { cur_pos = t * w.T; cur_end = cur_pos + w.qn[t]; }
+            }
+            if (!wave_done) {
+                const unsigned q = cur_pos + (unsigned)__popcll(need & lt);
+                if (!has && q < cur_end) {
+                    const float4 e0 = w.E0[q], e1 = w.E1[q], e2 = w.E2[q], e3 = w.E3[q];
+                    r.o = vec3(e0.x, e0.y, e0.z); r.d = vec3(e1.x, e1.y, e1.z);
+                    r.tr.o = r.o; r.tr.sX = e2.x; r.tr.sY = e2.y; r.tr.sZ = e2.z; r.tr.kZ = __float_as_int(e2.w);
+                    r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
+                    r.ox = r.o.x * r.idx; r.oy = r.o.y * r.idy; r.oz = r.o.z * r.idz;
+                    slot = __float_as_uint(e1.w);
+                    trav_init(ts, mesh, e0.w);
+                    has = true;
+                }
+                cur_pos += (unsigned)__popcll(need);
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (wave_done) break;
+            continue;
+        }
+        // while-while: walk inner nodes until every lane of the wave stands at a leaf (or is done), then
+        // test the leaves together; idle lanes are refilled at the top of the next round.
+        while (__ballot(has && trav_at_inner(ts))) {
+            if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
+        }
+        if (has) {
+            if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
+            if (ts.cur == HRT_TRAV_DONE) {
+                float t;
+                const int tri = trav_result(ts, t);
+                if (tri >= 0) { ((float*)&w.A[slot])[3] = t; w.H[slot] = make_int2(mesh_prim, tri); }
+                has = false;
+            }
+        }
+    }
+    if (STATS) {
+        const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
+        if (lane == 0) {
+            if (bt) atomicAdd(&counters->box_tests, (unsigned long long)bt);
+            if (tt) atomicAdd(&counters->tri_tests, (unsigned long long)tt);
+        }
+    }
+}
+
+// Remaining analytic prims [p0, n_prims), then main.cpp:46-76 for every live slot; the task's survivors are
+// compacted in place at the front of its list segment.
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_wf_shade(DScene sc, hrt_params pr, RenderMap map, unsigned n_local, int s0, int round,
+                                                  int p0, WfBuf w, DeviceCounters* counters, int count_rays) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned n_seg = 0;
+    PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
+    for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
+        const unsigned base = task * w.T;
+        const unsigned n = w.live[task];
+        unsigned out = base;
+        for (unsigned j0 = 0; j0 < n; j0 += 64) {
+            const unsigned j = j0 + lane;
+            bool alive = false;
+            unsigned slot = 0;
+            if (j < n) {
+                slot = round == 0 ? base + j : w.list[base + j];
+                n_seg++;
+                const float4 a = w.A[slot], b = w.B[slot], c = w.C[slot], dd = w.D[slot];
+                int2 h = w.H[slot];
+                PathState ps;
+                ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(b.x, b.y, b.z);
+                ps.atten = vec3(c.x, c.y, c.z); ps.result = vec3(dd.x, dd.y, dd.z); ps.bounce = round;
+                float closest = a.w;
+                const rng_ctx ctx = slot_ctx(pr, map, slot, n_local, s0, round);
+                prims_range_hit(sc, p0, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, h.x, h.y);
+                WorldHit wh; wh.prim = h.x; wh.sub = h.y; wh.t = closest;
+                const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
+                if (ended) {
+                    w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
+                } else {
+                    w.A[slot] = make_float4(ps.o.x, ps.o.y, ps.o.z, __builtin_huge_valf());
+                    w.B[slot] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f);
+                    w.C[slot] = make_float4(ps.atten.x, ps.atten.y, ps.atten.z, 0.0f);
+                    w.D[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
+                    w.H[slot] = make_int2(-1, -1);
+                    alive = true;
+                }
+            }
+            // in-place compaction: every write lands at or below positions this wave has already read
+            const unsigned long long m = __ballot(alive);
+            if (alive) w.list[out + (unsigned)__popcll(m & lt)] = slot;
+            out += (unsigned)__popcll(m);
+        }
+        if (lane == 0) w.live[task] = out - base;
+    }
+    if (count_rays) {   // scenes without a mesh have no k_wf_pre to count the segments
+        const unsigned seg = wave_sum(n_seg);
+        if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
+    }
+    if (STATS) {
+        const unsigned mh = wave_sum(pc.mesh_hits), ev = wave_sum(pc.env_lookups);
+        if (lane == 0) {
+            if (mh) atomicAdd(&counters->mesh_hits, (unsigned long long)mh);
+            if (ev) atomicAdd(&counters->env_lookups, (unsigned long long)ev);
+        }
+    }
+}
+
+// Per pixel: add the batch's samples IN SAMPLE ORDER (main.cpp:118-124); divide once all samples are in (main.cpp:126).
+__global__ __launch_bounds__(256) void k_wf_reduce(const float4* __restrict__ rad, unsigned n_local, int chunk, int first_chunk, int last_chunk,
+                                                   int spp, float* __restrict__ out, DeviceCounters* counters) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned lp = blockIdx.x * blockDim.x + threadIdx.x; lp < n_local; lp += stride) {
+        vec3 sum(0.0f);
+        if (!first_chunk) sum = vec3(out[3ull * lp], out[3ull * lp + 1], out[3ull * lp + 2]);
+        for (int s = 0; s < chunk; ++s) {
+            const float4 r = rad[(size_t)s * n_local + lp];
+            sum += vec3(r.x, r.y, r.z);
+        }
+        if (last_chunk) sum = sum / static_cast<float>(spp);
+        out[3ull * lp] = sum.x; out[3ull * lp + 1] = sum.y; out[3ull * lp + 2] = sum.z;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->samples, (unsigned long long)n_local * (unsigned long long)chunk);
+}
+
 }  // namespace
 
 // ===================================================================== host side of the ABI
@@ -217,19 +496,30 @@ hrt_status upload(T** dptr, const void* src, size_t bytes) {
 bool finite3(const float* p) { return p[0] == p[0] && p[1] == p[1] && p[2] == p[2]; }
 }  // namespace
 
+struct WfWorkspace {          // device workspace of the wavefront pipeline (grown on demand, kept with the scene)
+    void* base = nullptr;
+    size_t bytes = 0;
+    size_t slots = 0;
+    int depth = 0, n_mesh = 0;
+    WfBuf buf{};
+};
+
 struct hrt_scene {
     int device = 0;
     int n_cus = 256;
     DScene ds{};
     std::vector<void*> allocs;
+    std::vector<int> mesh_prims;   // indices of the HRT_PRIM_MESH entries of the world list, in list order
+    int n_prims = 0;
     DeviceCounters* d_counters = nullptr;
     unsigned* d_work = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    // events of launches not yet folded into kernel_ms
+    WfWorkspace wf;
+    // events of launches not yet folded into kernel_ms / traversal_ms
     struct Pending { hipEvent_t a, b; };
-    std::vector<Pending> pending;
-    double kernel_ms = 0.0;
-    uint64_t launches = 0;
+    std::vector<Pending> pending, pending_trav;
+    std::vector<hipEvent_t> event_pool;
+    double kernel_ms = 0.0, traversal_ms = 0.0;
+    uint64_t launches = 0, traversal_launches = 0;
 };
 
 namespace {
@@ -328,22 +618,126 @@ hrt_status check_params(const hrt_params* p) {
     return HRT_OK;
 }
 
-hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
-                            hipStream_t stream) {
-    if (map.total_items <= 0) return HRT_OK;
+hrt_status get_event(hrt_scene* sc, hipEvent_t* ev) {
+    if (!sc->event_pool.empty()) { *ev = sc->event_pool.back(); sc->event_pool.pop_back(); return HRT_OK; }
+    HIPCHK(hipEventCreate(ev));
+    return HRT_OK;
+}
+
+hrt_status launch_megakernel(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
+                             hipStream_t stream) {
     HIPCHK(hipMemsetAsync(sc->d_work, 0, sizeof(unsigned), stream));
     int blocks = (map.total_items + HRT_BLOCK - 1) / HRT_BLOCK;
     const int cap = sc->n_cus * 8;
     if (blocks > cap) blocks = cap;
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    HIPCHK(hipEventRecord(a, stream));
     if (pr->flags & HRT_FLAG_STATS)
         hipLaunchKernelGGL(k_pathtrace<true>, dim3(blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *cam, *pr, map, d_out, sc->d_counters, sc->d_work);
     else
         hipLaunchKernelGGL(k_pathtrace<false>, dim3(blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *cam, *pr, map, d_out, sc->d_counters, sc->d_work);
     HIPCHK(hipGetLastError());
+    return HRT_OK;
+}
+
+size_t wf_max_slots() {
+    size_t cap = (size_t)48 << 20;                       // 48 Mi slots x 160 B = 7.5 GiB of the 288 GB
+    if (const char* e = getenv("HRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) cap = (size_t)v; }
+    return cap;
+}
+
+hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
+    WfWorkspace& w = sc->wf;
+    const int n_mesh = (int)sc->mesh_prims.size();
+    if (w.base && w.slots >= slots && w.depth >= depth && w.n_mesh == n_mesh) return HRT_OK;
+    if (w.base) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(w.base); w = WfWorkspace(); }
+    const size_t max_tasks = slots / 256 + 1;
+    const size_t head_words = (size_t)depth * (n_mesh > 0 ? n_mesh : 1);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t f4 = al(slots * sizeof(float4));
+    const size_t total = 9 * f4 + al(slots * sizeof(int2)) + al(slots * sizeof(unsigned)) + 2 * al(max_tasks * sizeof(unsigned)) +
+                         al(head_words * sizeof(unsigned));
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, total);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string("hipMalloc(wavefront workspace): ") + hipGetErrorString(e));
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { char* q = p; p += bytes; return q; };
+    w.buf.A = (float4*)take(f4); w.buf.B = (float4*)take(f4); w.buf.C = (float4*)take(f4); w.buf.D = (float4*)take(f4);
+    w.buf.E0 = (float4*)take(f4); w.buf.E1 = (float4*)take(f4); w.buf.E2 = (float4*)take(f4); w.buf.E3 = (float4*)take(f4);
+    w.buf.rad = (float4*)take(f4);
+    w.buf.H = (int2*)take(al(slots * sizeof(int2)));
+    w.buf.list = (unsigned*)take(al(slots * sizeof(unsigned)));
+    w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
+    w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
+    w.buf.heads = (unsigned*)take(al(head_words * sizeof(unsigned)));
+    w.base = base; w.bytes = total; w.slots = slots; w.depth = depth; w.n_mesh = n_mesh;
+    return HRT_OK;
+}
+
+// render() as the wavefront pipeline: see the comment above k_wf_gen.
+hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
+                            hipStream_t stream) {
+    const unsigned n_local = (unsigned)map.rw * (unsigned)map.rh;
+    const int D = pr->max_depth;
+    const int n_mesh = (int)sc->mesh_prims.size();
+    size_t cap = wf_max_slots();
+    int chunk = (int)std::min<size_t>((size_t)pr->samples, std::max<size_t>(1, cap / n_local));
+    const size_t slots = (size_t)n_local * chunk;
+    if (slots >= ((size_t)1 << 32) - 4096) return fail(HRT_ERR_UNSUPPORTED, "tile too large for 32-bit slot ids");
+    hrt_status st = wf_reserve(sc, slots, D);
+    if (st != HRT_OK) return st;
+    WfBuf w = sc->wf.buf;
+    const size_t head_words = (size_t)D * (n_mesh > 0 ? n_mesh : 1);
+    const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
+    const int ext_blocks = sc->n_cus * 4;
+
+    for (int s0 = 0; s0 < pr->samples; s0 += chunk) {
+        const int c = std::min(chunk, pr->samples - s0);
+        const unsigned n_slots = n_local * (unsigned)c;
+        // task size: ~64 tasks per CU so the tail is short, between 256 and 4096 slots, a multiple of 64
+        size_t T = (n_slots / ((size_t)sc->n_cus * 64) + 63) & ~(size_t)63;
+        T = std::min<size_t>(4096, std::max<size_t>(256, T));
+        w.T = (unsigned)T;
+        w.n_tasks = (unsigned)((n_slots + T - 1) / T);
+        const int dense = (int)std::min<size_t>((n_slots + 255) / 256, (size_t)sc->n_cus * 8);
+        const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
+        HIPCHK(hipMemsetAsync(w.heads, 0, head_words * sizeof(unsigned), stream));
+        hipLaunchKernelGGL(k_wf_gen, dim3(dense), dim3(256), 0, stream, *cam, *pr, map, n_local, s0, n_slots, w);
+        for (int r = 0; r < D; ++r) {
+            int pb = 0;
+            for (int m = 0; m < n_mesh; ++m) {
+                const int mp = sc->mesh_prims[m];
+                unsigned* head = w.heads + (size_t)r * n_mesh + m;
+                if (stats) hipLaunchKernelGGL(k_wf_pre<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, mp, mp, w, sc->d_counters);
+                else hipLaunchKernelGGL(k_wf_pre<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, mp, mp, w, sc->d_counters);
+                hipEvent_t ea = nullptr, eb = nullptr;
+                if (timing) { st = get_event(sc, &ea); if (st != HRT_OK) return st; st = get_event(sc, &eb); if (st != HRT_OK) return st; HIPCHK(hipEventRecord(ea, stream)); }
+                if (stats) hipLaunchKernelGGL(k_wf_ext<true>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, w, head, sc->d_counters);
+                else hipLaunchKernelGGL(k_wf_ext<false>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, w, head, sc->d_counters);
+                if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
+                pb = mp + 1;
+            }
+            const int count_rays = n_mesh == 0 ? 1 : 0;
+            if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, w, sc->d_counters, count_rays);
+            else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, w, sc->d_counters, count_rays);
+        }
+        const int rblocks = (int)std::min<size_t>((n_local + 255) / 256, (size_t)sc->n_cus * 8);
+        hipLaunchKernelGGL(k_wf_reduce, dim3(rblocks), dim3(256), 0, stream, w.rad, n_local, c, s0 == 0 ? 1 : 0, s0 + c >= pr->samples ? 1 : 0, pr->samples, d_out, sc->d_counters);
+        HIPCHK(hipGetLastError());
+    }
+    return HRT_OK;
+}
+
+hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
+                            hipStream_t stream) {
+    if (map.total_items <= 0) return HRT_OK;
+    hipEvent_t a, b;
+    hrt_status st = get_event(sc, &a);
+    if (st != HRT_OK) return st;
+    st = get_event(sc, &b);
+    if (st != HRT_OK) return st;
+    HIPCHK(hipEventRecord(a, stream));
+    st = (pr->flags & HRT_FLAG_MEGAKERNEL) ? launch_megakernel(sc, cam, pr, map, d_out, stream)
+                                           : launch_wavefront(sc, cam, pr, map, d_out, stream);
+    if (st != HRT_OK) return st;
     HIPCHK(hipEventRecord(b, stream));
     sc->pending.push_back({a, b});
     sc->launches++;
@@ -356,10 +750,18 @@ hrt_status fold_pending(hrt_scene* sc) {
         float ms = 0.0f;
         HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
         sc->kernel_ms += ms;
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
+        sc->event_pool.push_back(p.a); sc->event_pool.push_back(p.b);
     }
     sc->pending.clear();
+    for (auto& p : sc->pending_trav) {
+        HIPCHK(hipEventSynchronize(p.b));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+        sc->traversal_ms += ms;
+        sc->traversal_launches++;
+        sc->event_pool.push_back(p.a); sc->event_pool.push_back(p.b);
+    }
+    sc->pending_trav.clear();
     return HRT_OK;
 }
 
@@ -396,6 +798,9 @@ void hrt_scene_destroy(hrt_scene* sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
     for (auto& p : sc->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : sc->pending_trav) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : sc->event_pool) (void)hipEventDestroy(e);
+    if (sc->wf.base) (void)hipFree(sc->wf.base);
     for (void* p : sc->allocs) (void)hipFree(p);
     delete sc;
 }
@@ -454,6 +859,9 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     sc->ds.texels_u8 = d_u8; sc->ds.texels_f32 = d_f32;
     sc->ds.n_prims = (int32_t)f->n_prims;
     sc->ds.background_tex = f->background_tex;
+    sc->n_prims = (int)f->n_prims;
+    for (uint32_t i = 0; i < f->n_prims; ++i)
+        if (f->prims[i].kind == HRT_PRIM_MESH) sc->mesh_prims.push_back((int)i);
     *out = sc;
     return HRT_OK;
 }
@@ -501,7 +909,8 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     stats->rays = c.rays; stats->samples = c.samples; stats->box_tests = c.box_tests; stats->tri_tests = c.tri_tests;
     stats->mesh_hits = c.mesh_hits; stats->env_lookups = c.env_lookups;
     stats->kernel_ms = sc->kernel_ms; stats->launches = sc->launches;
-    sc->kernel_ms = 0.0; sc->launches = 0;
+    stats->traversal_ms = sc->traversal_ms; stats->traversal_launches = sc->traversal_launches;
+    sc->kernel_ms = 0.0; sc->launches = 0; sc->traversal_ms = 0.0; sc->traversal_launches = 0;
     return HRT_OK;
 }
 

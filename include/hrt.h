@@ -213,8 +213,12 @@ typedef struct hrt_params {
 
 /* hrt_params.flags */
 enum {
-    HRT_FLAG_STATS = 1u << 0   /* also count box_tests / tri_tests / mesh_hits / env_lookups (the counting
-                                  build of the path-trace kernel; rays and samples are always counted) */
+    HRT_FLAG_STATS = 1u << 0,  /* also count box_tests / tri_tests / mesh_hits / env_lookups (the counting
+                                  build of the kernels; rays and samples are always counted) */
+    HRT_FLAG_MEGAKERNEL = 1u << 1, /* render with the single persistent-lanes kernel (k_pathtrace) instead of the
+                                  default wavefront pipeline (k_wf_*); results are bit-identical */
+    HRT_FLAG_TIMING = 1u << 2  /* wavefront pipeline: also time the traversal kernel's launches with HIP events
+                                  (hrt_stats.traversal_ms) */
 };
 
 typedef struct hrt_rect { int32_t x0, y0, w, h; } hrt_rect;   /* y0 = row index from the TOP (pIdx / W) */
@@ -226,9 +230,12 @@ typedef struct hrt_stats {
     uint64_t tri_tests;  /* triangles tested (36 B each)                  */
     uint64_t mesh_hits;  /* segments whose closest hit is a mesh triangle (60 B attrs) */
     uint64_t env_lookups;/* segments that escaped to an fp32 env map (12 B) */
-    double kernel_ms;    /* path-trace kernel time, summed over `launches`, from HIP events recorded on the
-                            launch stream directly around each kernel launch */
-    uint64_t launches;   /* path-trace kernel launches accumulated in this record */
+    double kernel_ms;    /* path-trace time (megakernel launch, or the whole wavefront pipeline of one render
+                            call), summed over `launches`, from HIP events recorded on the launch stream */
+    uint64_t launches;   /* render calls (megakernel launches / wavefront pipeline runs) accumulated here */
+    double traversal_ms; /* wavefront pipeline with HRT_FLAG_TIMING: time of the BVH traversal kernel (k_wf_ext),
+                            summed over its `traversal_launches` launches, from HIP events around each launch */
+    uint64_t traversal_launches;
 } hrt_stats;
 
 typedef struct hrt_hit {          /* hitRecord (hittable.h:8-25) as seen by rayColour */

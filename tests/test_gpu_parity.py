@@ -120,15 +120,17 @@ def test_closest_hit_from_surface_points(teapot):
     assert np.array_equal(g["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))
 
 
+@pytest.mark.parametrize("path", ["wavefront", "megakernel"])
 @pytest.mark.parametrize("quirks", ["reference", "fixed"])
-def test_image_parity_teapot(teapot, quirks):
-    """render() (main.cpp:81-140): 96x96, 16 spp, depth 50.  Linear fp32 film, GPU vs oracle."""
+def test_image_parity_teapot(teapot, quirks, path):
+    """render() (main.cpp:81-140): 96x96, 16 spp, depth 50.  Linear fp32 film, GPU vs oracle, for both
+    render paths (wavefront pipeline k_wf_* = default, persistent-lanes megakernel k_pathtrace)."""
     from hobbyraytracer_amd import api
     hs, dev, world = teapot
     q = api.QUIRKS_REFERENCE if quirks == "reference" else api.QUIRKS_FIXED
     W = H = 96
     cam = hs.camera(W, H)
-    params = api.default_params(W, H, 16, quirks=q, stats=True)
+    params = api.default_params(W, H, 16, quirks=q, stats=True, megakernel=(path == "megakernel"))
     img, st = dev.render_tile(cam, params)
     ref, st_ref = world.render_tile(cam, params)
     assert st.samples == st_ref.samples == W * H * 16
@@ -144,13 +146,14 @@ def test_image_parity_teapot(teapot, quirks):
     assert np.array_equal(dev.resolve_u8(img), orc.resolve_u8(ref))
 
 
-def test_tiling_invariance(teapot):
+@pytest.mark.parametrize("path", ["wavefront", "megakernel"])
+def test_tiling_invariance(teapot, path):
     """Any tiling / stripe partition gives the bit-identical film (RNG keyed by absolute pixel)."""
     from hobbyraytracer_amd import api
     hs, dev, world = teapot
     W, H = 80, 56
     cam = hs.camera(W, H)
-    params = api.default_params(W, H, 4)
+    params = api.default_params(W, H, 4, megakernel=(path == "megakernel"))
     full, _ = dev.render_tile(cam, params)
     # rect tiles
     out = np.zeros_like(full)
@@ -167,6 +170,26 @@ def test_tiling_invariance(teapot):
             assert part.shape[0] == len(rows)
             out[rows] = part
         assert np.array_equal(out.view(np.uint32), full.view(np.uint32)), f"G={G}"
+
+
+def test_wavefront_sample_chunking_and_paths_agree(teapot, monkeypatch):
+    """The wavefront pipeline batches samples when (pixels x spp) exceeds its slot budget; partial sums carry
+    over in the film buffer in sample order, so any chunking gives the same bits as one batch and as the
+    megakernel.  Counters agree too."""
+    from hobbyraytracer_amd import api
+    hs, dev, world = teapot
+    W, H, spp = 64, 48, 10
+    cam = hs.camera(W, H)
+    one, s1 = dev.render_tile(cam, api.default_params(W, H, spp, stats=True))
+    mega, s2 = dev.render_tile(cam, api.default_params(W, H, spp, stats=True, megakernel=True))
+    monkeypatch.setenv("HRT_WF_MAX_SLOTS", str(W * H * 3))       # 3 samples per batch -> 4 batches (3+3+3+1)
+    chunked, s3 = dev.render_tile(cam, api.default_params(W, H, spp, stats=True))
+    monkeypatch.delenv("HRT_WF_MAX_SLOTS")
+    assert np.array_equal(one.view(np.uint32), mega.view(np.uint32))
+    assert np.array_equal(one.view(np.uint32), chunked.view(np.uint32))
+    for a in (s2, s3):
+        assert (a.rays, a.samples, a.box_tests, a.tri_tests, a.mesh_hits, a.env_lookups) == \
+               (s1.rays, s1.samples, s1.box_tests, s1.tri_tests, s1.mesh_hits, s1.env_lookups)
 
 
 def test_resolve_u8(built):

@@ -14,15 +14,16 @@ SCENES = {  # name -> (W, H, spp)
 }
 
 
+@pytest.mark.parametrize("path", ["wavefront", "megakernel"])
 @pytest.mark.parametrize("quirks", ["reference", "fixed"])
 @pytest.mark.parametrize("scene", sorted(SCENES))
-def test_image_parity(built, assets, scenes_dir, scene, quirks):
+def test_image_parity(built, assets, scenes_dir, scene, quirks, path):
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
     W, H, spp = SCENES[scene]
     hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
     q = api.QUIRKS_REFERENCE if quirks == "reference" else api.QUIRKS_FIXED
-    params = api.default_params(W, H, spp, quirks=q, stats=True)
+    params = api.default_params(W, H, spp, quirks=q, stats=True, megakernel=(path == "megakernel"))
     cam = hs.camera(W, H)
     dev = api.DeviceScene(hs.flat_ptr, 0)
     img, st = dev.render_tile(cam, params)
