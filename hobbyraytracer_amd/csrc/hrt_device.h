@@ -31,7 +31,40 @@ struct DScene {
     const float* texels_f32;
     int32_t n_prims;
     int32_t background_tex;
+    // Copies of the four small tables for PER-LANE indexed lookups (hit prim -> mesh -> material ->
+    // texture is a chain of dependent gathers): kernels stage them in LDS once per workgroup
+    // (stage_tables) so each hop costs an LDS read (~64 cycles) instead of an L2 round trip.  Wave-uniform
+    // walks over the tables (the world-list loop) keep using the global pointers above, which the compiler
+    // turns into scalar loads.  Host code and tables too large for LDS point these at the global arrays.
+    const hrt_prim* lprims;
+    const hrt_material* lmats;
+    const hrt_texture* ltexs;
+    const hrt_mesh* lmeshes;
+    int32_t n_mats, n_texs, n_meshes;
 };
+
+#define HRT_TABLE_LDS_BYTES 12288
+#if defined(__HIPCC__)
+// Copies prims / mats / texs / meshes into `buf` (HRT_TABLE_LDS_BYTES of LDS, 16-byte aligned) when they
+// fit, and repoints sc.l*; every thread of the block must call it (it ends with a barrier).
+__device__ inline void stage_tables(DScene& sc, uint32_t* buf) {
+    const uint32_t wp = (uint32_t)(sc.n_prims * sizeof(hrt_prim) + 15) / 16 * 4, wm = (uint32_t)(sc.n_mats * sizeof(hrt_material) + 15) / 16 * 4;
+    const uint32_t wt = (uint32_t)(sc.n_texs * sizeof(hrt_texture) + 15) / 16 * 4, wx = (uint32_t)(sc.n_meshes * sizeof(hrt_mesh) + 15) / 16 * 4;
+    if ((wp + wm + wt + wx) * 4u <= HRT_TABLE_LDS_BYTES) {
+        const uint32_t* src[4] = {(const uint32_t*)sc.prims, (const uint32_t*)sc.mats, (const uint32_t*)sc.texs, (const uint32_t*)sc.meshes};
+        const uint32_t words[4] = {(uint32_t)(sc.n_prims * sizeof(hrt_prim)) / 4, (uint32_t)(sc.n_mats * sizeof(hrt_material)) / 4,
+                                   (uint32_t)(sc.n_texs * sizeof(hrt_texture)) / 4, (uint32_t)(sc.n_meshes * sizeof(hrt_mesh)) / 4};
+        const uint32_t off[4] = {0, wp, wp + wm, wp + wm + wt};
+        for (int k = 0; k < 4; ++k)
+            for (uint32_t i = threadIdx.x; i < words[k]; i += blockDim.x) buf[off[k] + i] = src[k][i];
+        sc.lprims = (const hrt_prim*)(buf + off[0]);
+        sc.lmats = (const hrt_material*)(buf + off[1]);
+        sc.ltexs = (const hrt_texture*)(buf + off[2]);
+        sc.lmeshes = (const hrt_mesh*)(buf + off[3]);
+    }
+    __syncthreads();
+}
+#endif
 
 struct DRec {  // hitRecord (hittable.h:8-25)
     vec3 p, normal;
@@ -529,7 +562,7 @@ __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o,
 
 // Rebuilds the winner's hitRecord exactly as the reference's call chain does.
 __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, DRec& rec) {
-    const hrt_prim& pr = sc.prims[wh.prim];
+    const hrt_prim& pr = sc.lprims[wh.prim];
     vec3 lo = o, ld = d;
     vec3 dirs[HRT_MAX_XFORMS];
     const int n = pr.n_xforms;
@@ -540,7 +573,7 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     rec.mat = pr.material;
     rec.frontFace = true;
     const int kind = pr.kind;
-    if (kind == HRT_PRIM_MESH) tri_rec(sc, sc.meshes[pr.mesh], wh.sub, lo, ld, quirks, rec);
+    if (kind == HRT_PRIM_MESH) tri_rec(sc, sc.lmeshes[pr.mesh], wh.sub, lo, ld, quirks, rec);
     else if (kind == HRT_PRIM_SPHERE) sphere_rec(pr.p, lo, ld, wh.t, rec);
     else if (kind == HRT_PRIM_BOX) box_rec(pr.p, lo, ld, wh.t, wh.sub, rec);
     else if (kind == HRT_PRIM_MEDIUM) {  // constantMedium.cpp:30-36
@@ -578,7 +611,7 @@ __device__ inline vec3 tex_leaf(const DScene& sc, const hrt_texture& t, float u,
 __device__ inline vec3 tex_value(const DScene& sc, int tex, float u, float v, vec3 p) {
     // CheckeredTexture (texture.cpp:17-28) may nest; bounded walk instead of recursion
     for (int depth = 0; depth < 4; ++depth) {
-        const hrt_texture& t = sc.texs[tex];
+        const hrt_texture& t = sc.ltexs[tex];
         if (t.kind != HRT_TEX_CHECKER) return tex_leaf(sc, t, u, v);
         float sines = gsin(10 * p.x) * gsin(10 * p.y) * gsin(10 * p.z);
         tex = (sines < 0) ? t.odd : t.even;
@@ -598,7 +631,7 @@ __device__ inline float matscalar_value(const DScene& sc, const hrt_matscalar& m
 // Returns false when the path ends (DiffuseLight, absorbed Metal).
 __device__ inline bool material_scatter(const DScene& sc, const DRec& rec, vec3 rin_d, const rng_ctx& ctx, vec3& emitted,
                                         vec3& attenuation, vec3& so, vec3& sd) {
-    const hrt_material& m = sc.mats[rec.mat];
+    const hrt_material& m = sc.lmats[rec.mat];
     int kind = m.kind;
     emitted = vec3(0.0f);
     if (kind == HRT_MAT_DIFFUSE_LIGHT) {  // material.h:96-104
@@ -697,11 +730,11 @@ template <bool STATS>
 __device__ inline bool path_shade(const DScene& sc, const hrt_params& pr, const rng_ctx& ctx, PathState& ps, const WorldHit& wh,
                                   PathCounters& pc) {
     if (wh.prim < 0) {
-        if (STATS && sc.texs[sc.background_tex].kind == HRT_TEX_ENV) pc.env_lookups++;
+        if (STATS && sc.ltexs[sc.background_tex].kind == HRT_TEX_ENV) pc.env_lookups++;
         ps.result += ps.atten * background_value(sc, ps.d);
         return true;
     }
-    if (STATS && sc.prims[wh.prim].kind == HRT_PRIM_MESH) pc.mesh_hits++;
+    if (STATS && sc.lprims[wh.prim].kind == HRT_PRIM_MESH) pc.mesh_hits++;
     DRec rec;
     world_rec(sc, wh, ps.o, ps.d, pr.quirks, rec);
     vec3 emitted, attenuation, so, sd;

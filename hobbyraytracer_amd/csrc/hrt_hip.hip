@@ -37,7 +37,22 @@ struct RenderMap {
     int32_t R, rank, G;      // stripes
     int32_t tiles_x;         // ceil(rw / 8)
     int32_t total_items;     // tiles_x * ceil(rh / 8) * 64
+    // exact division of 32-bit numbers by rw and by rw*rh as multiply-high + shift (host-computed magic
+    // numbers, fastdiv below): the wavefront kernels turn slot ids into (sample, pixel) for every path
+    uint64_t m_rw, m_nl;
 };
+
+// floor(x / d) for any 32-bit x: with m = floor(2^64 / d) + 1 the product's high half is exact for every
+// x < 2^32 (the error term x / 2^64 * d stays below 1 / d).  d = 1 needs no magic.
+__host__ __device__ inline uint32_t fastdiv(uint32_t x, uint32_t d, uint64_t m) {
+    if (d == 1) return x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__umul64hi(m, (uint64_t)x);
+#else
+    return (uint32_t)(((unsigned __int128)m * x) >> 64);
+#endif
+}
+inline uint64_t fastdiv_magic(uint32_t d) { return d <= 1 ? 0 : (uint64_t)(~0ull / d) + 1; }
 
 struct DeviceCounters {      // 64-bit accumulators in device memory
     unsigned long long rays, samples, box_tests, tri_tests, mesh_hits, env_lookups;
@@ -54,8 +69,10 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_pathtrace(DScene sc, hrt_camera c
                                                          float* __restrict__ out, DeviceCounters* counters,
                                                          unsigned* work_counter) {
     __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
     int* stack = s_stack + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
+    stage_tables(sc, s_tables);
 
     // lane state
     int out_index = -1;          // local pixel (row-major in the region); -1 = lane holds no pixel
@@ -145,7 +162,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_closest_hit(DScene sc, hrt_params
                                                            const float* __restrict__ rd, float t_min, float t_max,
                                                            uint32_t pixel0, hrt_hit* __restrict__ out) {
     __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
     int* stack = s_stack + threadIdx.x;
+    stage_tables(sc, s_tables);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const vec3 o(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
@@ -190,132 +209,180 @@ __global__ void k_math_probe(int op, long long n, const float* __restrict__ in, 
 
 // ===================================================================== wavefront pipeline (default path)
 // The same render() as k_pathtrace, organised for wave density instead of per-lane persistence:
-//   * every (pixel, sample) of the batch owns a SLOT of path state in HBM (the 288 GB make a whole
-//     640x640x100 frame = 41 M slots = 6.7 GB affordable), so samples run in parallel;
-//   * one ROUND = one path segment of every live slot: k_wf_pre (analytic prims in list order, mesh-space
-//     ray setup, root-box filter) -> k_wf_ext (persistent BVH traversal of the surviving rays only) ->
-//     k_wf_shade (remaining prims, hitRecord, scatter, compaction of the survivors);
-//   * k_wf_reduce adds each pixel's samples in sample order (main.cpp:118-126), so the fp32 sum has the
-//     reference's order although the samples were traced concurrently.
-// Lists are TASK-SEGMENTED: slots are cut into tasks of `T` consecutive slots; a task is always handled
-// by one wave, which compacts its live slots / queued rays in place inside the task's segment using
-// ballots only.  No list append ever touches a global atomic (a single address sustains only ~88 atomics
-// per microsecond on this chip: MI355X_MICROARCH.md "dequeue"); the traversal kernel pulls whole tasks,
-// one atomic per task.  Everything is driven by DEVICE-side counts: the host enqueues max_depth rounds
-// back to back with no synchronisation.
+//   * every (pixel, sample) of the batch owns a SLOT (the 288 GB of HBM make a whole 640x640x100 frame
+//     = 41 M concurrent paths affordable), so samples run in parallel; k_wf_reduce adds each pixel's
+//     samples in sample order (main.cpp:118-126), so the fp32 sum keeps the reference's order;
+//   * one ROUND = one path segment of every live path:
+//       k_wf_ext    persistent BVH traversal of the rays that passed the root-box filter
+//       k_wf_shade  remaining analytic prims, hitRecord, emitted/scatter (main.cpp:46-76); survivors get
+//                   their NEXT segment prepared in the same kernel: analytic prims in front of the first
+//                   mesh (list order), mesh-space ray, root-box filter, traversal record
+//     (k_wf_gen does that preparation for the camera rays; scenes with several meshes run k_wf_pre +
+//      k_wf_ext once more per further mesh, in world-list order);
+//   * path state is PHYSICALLY COMPACTED every round (ping-pong buffers): a survivor writes its 64-byte
+//     state to the next free position of its task's segment, so every kernel reads and writes dense,
+//     coalesced records whatever fraction of the paths is still alive;
+//   * lists are TASK-SEGMENTED: slots are cut into tasks of T consecutive positions, a task is always
+//     handled by one wave, and compaction inside a task uses ballots only.  No append touches a global
+//     atomic (one address sustains only ~88 atomics/us on this chip: MI355X_MICROARCH.md "dequeue"); the
+//     traversal kernel pulls whole tasks, one atomic each.
+// Everything is driven by DEVICE-side counts: the host enqueues max_depth rounds with no synchronisation.
 struct WfBuf {
-    float4 *A, *B, *C, *D;       // A = o.xyz, closest t | B = d.xyz, - | C = attenuation | D = result
-    int2* H;                     // hit prim, sub (triangle / box side)
-    float4 *E0, *E1, *E2, *E3;   // traversal records (at the queue position): o' tmax | d' slot | sX sY sZ kZ | 1/d'
-    float4* rad;                 // radiance of the finished path of each slot
-    unsigned* list;              // live slots of task k at [k*T, k*T + live[k])  (implicit identity in round 0)
-    unsigned* live;              // per task: live slots
-    unsigned* qn;                // per task: rays queued for the current mesh at [k*T, k*T + qn[k]) of E0..E3
+    // live-path state, two copies (read parity r & 1, written parity (r + 1) & 1), indexed by POSITION:
+    float4* S0[2];   // o.xyz, closest t
+    float4* S1[2];   // d.xyz, slot (bits)
+    float4* S2[2];   // attenuation, hit prim (bits)
+    int* S3[2];      // hit sub = triangle / box side
+    // The running `result` of main.cpp:41 is NOT carried: Material::emitted is non-zero only for DiffuseLight
+    // (material.h:67-70, 101-104), which never scatters (material.h:96-99), so result is still exactly 0 when a
+    // path reaches its last segment and `0 + atten * x` is exact.
+    float4 *E0, *E1, *E2, *E3;   // traversal records at [k*T, k*T + qn[k]): o' tmax | d' position | sX sY sZ kZ | 1/d'
+    float4* rad;                 // radiance of the finished path of each SLOT
+    unsigned* live;              // per task: live paths, at positions [k*T, k*T + live[k])
+    unsigned* qn;                // per task: rays queued for the current mesh
     unsigned* heads;             // per (round, mesh): next task for k_wf_ext
     unsigned T, n_tasks;
 };
+struct WfScene {                 // world-list split points (host-computed)
+    int first_mesh;              // index of the first HRT_PRIM_MESH, or n_prims when there is none
+    int rest;                    // first prim after the last mesh (n_prims when there is no mesh)
+    int has_mesh;
+};
 
 __device__ inline void slot_pixel(const RenderMap& map, unsigned lp, int& px, int& py) {
-    const int lx = (int)(lp % (unsigned)map.rw), ly = (int)(lp / (unsigned)map.rw);
+    const int ly = (int)fastdiv(lp, (unsigned)map.rw, map.m_rw);
+    const int lx = (int)(lp - (unsigned)ly * (unsigned)map.rw);
     if (map.mode == 0) { px = map.x0 + lx; py = map.y0 + ly; }
     else { const int b = ly / map.R; px = lx; py = (b * map.G + map.rank) * map.R + (ly - b * map.R); }
 }
 __device__ inline rng_ctx slot_ctx(const hrt_params& pr, const RenderMap& map, unsigned slot, unsigned n_local, int s0, int bounce) {
     int px, py;
-    slot_pixel(map, slot % n_local, px, py);
+    const unsigned sl = fastdiv(slot, n_local, map.m_nl);
+    slot_pixel(map, slot - sl * n_local, px, py);
     rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi;
-    ctx.pixel = (uint32_t)(py * pr.width + px); ctx.sample = (uint32_t)(s0 + (int)(slot / n_local)); ctx.bounce = (uint32_t)bounce;
+    ctx.pixel = (uint32_t)(py * pr.width + px); ctx.sample = (uint32_t)(s0 + (int)sl); ctx.bounce = (uint32_t)bounce;
     return ctx;
 }
 
-__global__ __launch_bounds__(256) void k_wf_gen(hrt_camera cam, hrt_params pr, RenderMap map, unsigned n_local, int s0,
-                                                unsigned n_slots, WfBuf w) {
-    const unsigned stride = gridDim.x * blockDim.x;
-    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned k = gid; k < w.n_tasks; k += stride) {
-        const unsigned first = k * w.T;
-        w.live[k] = first < n_slots ? min(w.T, n_slots - first) : 0u;
-    }
-    for (unsigned slot = gid; slot < n_slots; slot += stride) {
-        int px, py;
-        slot_pixel(map, slot % n_local, px, py);
-        rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi;
-        ctx.pixel = (uint32_t)(py * pr.width + px); ctx.sample = (uint32_t)(s0 + (int)(slot / n_local)); ctx.bounce = 0;
-        PathState ps;
-        path_begin(cam, pr, px, py, ctx, ps);
-        w.A[slot] = make_float4(ps.o.x, ps.o.y, ps.o.z, __builtin_huge_valf());
-        w.B[slot] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f);
-        w.C[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        w.D[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        w.H[slot] = make_int2(-1, -1);
-    }
+// Preparation of one segment: analytic prims [p0, p1) in list order (closest-so-far semantics of
+// hittableList.cpp:12-19), then the ray in the space of mesh prim `mesh_prim` and the root-box filter.
+template <bool STATS>
+__device__ inline bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
+                                  const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled) {
+    prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
+    if (mesh_prim < 0) return false;
+    const hrt_prim& mp = sc.prims[mesh_prim];
+    const hrt_mesh& mesh = sc.meshes[mp.mesh];
+    vec3 lo = o, ld = d;
+    for (int k = 0; k < mp.n_xforms; ++k) xf_apply(mp.xf[k], lo, ld, pr.quirks);
+    mr = mesh_ray_setup(lo, ld, pr.quirks);
+    const bool enq = root_may_hit(sc, mesh, mr, trav_t_lo(pr.t_min, pr.quirks), closest);
+    if (STATS && !enq && mesh.node_count) n_culled++;
+    return enq;
+}
+__device__ inline void wf_store_record(const WfBuf& w, unsigned q, const MeshRay& mr, float closest, unsigned pos) {
+    w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, closest);
+    w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pos));
+    w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
+    w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, 0.0f);
+}
+__device__ inline void wf_store_state(const WfBuf& w, int par, unsigned pos, const PathState& ps, float closest, unsigned slot, int prim, int sub) {
+    w.S0[par][pos] = make_float4(ps.o.x, ps.o.y, ps.o.z, closest);
+    w.S1[par][pos] = make_float4(ps.d.x, ps.d.y, ps.d.z, __uint_as_float(slot));
+    w.S2[par][pos] = make_float4(ps.atten.x, ps.atten.y, ps.atten.z, __int_as_float(prim));
+    w.S3[par][pos] = sub;
 }
 
-// Analytic prims [p0, p1) in list order, then the mesh-space ray of prim `mesh_prim` + root filter + enqueue.
+// Camera rays (main.cpp:115-123) of every slot of the batch + the preparation of their first segment.
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, RenderMap map, unsigned n_local, int s0, int round,
-                                                int p0, int p1, int mesh_prim, WfBuf w, DeviceCounters* counters) {
+__global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_params pr, RenderMap map, WfScene ws, unsigned n_local, int s0,
+                                                unsigned n_slots, WfBuf w, DeviceCounters* counters) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned n_culled = 0, n_seg = 0;
-    const hrt_prim& mp = sc.prims[mesh_prim];
-    const hrt_mesh mesh = sc.meshes[mp.mesh];
-    const float t_lo = trav_t_lo(pr.t_min, pr.quirks);
+    unsigned n_culled = 0;
     for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
         const unsigned base = task * w.T;
-        const unsigned n = w.live[task];
+        const unsigned n = base < n_slots ? min(w.T, n_slots - base) : 0u;
         unsigned qpos = base;
         for (unsigned j0 = 0; j0 < n; j0 += 64) {
             const unsigned j = j0 + lane;
-            bool enqueue = false;
-            unsigned slot = 0;
+            bool enq = false;
             MeshRay mr;
-            float closest = 0.0f;
+            float closest = __builtin_huge_valf();
+            const unsigned slot = base + j;
             if (j < n) {
-                slot = round == 0 ? base + j : w.list[base + j];
-                const float4 a = w.A[slot], b = w.B[slot];
-                const vec3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
-                closest = a.w;
-                int2 h = w.H[slot];
-                const int prim0 = h.x;
-                if (p0 == 0) n_seg++;
-                if (p1 > p0) {
-                    const rng_ctx ctx = slot_ctx(pr, map, slot, n_local, s0, round);
-                    prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, h.x, h.y);
-                    if (h.x != prim0) { ((float*)&w.A[slot])[3] = closest; w.H[slot] = h; }
-                }
-                vec3 lo = o, ld = d;
-                for (int k = 0; k < mp.n_xforms; ++k) xf_apply(mp.xf[k], lo, ld, pr.quirks);
-                mr = mesh_ray_setup(lo, ld, pr.quirks);
-                enqueue = root_may_hit(sc, mesh, mr, t_lo, closest);
-                if (STATS && !enqueue && mesh.node_count) n_culled++;
+                int px, py;
+                const unsigned sl = fastdiv(slot, n_local, map.m_nl);
+                slot_pixel(map, slot - sl * n_local, px, py);
+                rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi;
+                ctx.pixel = (uint32_t)(py * pr.width + px); ctx.sample = (uint32_t)(s0 + (int)sl); ctx.bounce = 0;
+                PathState ps;
+                path_begin(cam, pr, px, py, ctx, ps);
+                int prim = -1, sub = -1;
+                enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
+                wf_store_state(w, 0, slot, ps, closest, slot, prim, sub);
             }
-            const unsigned long long m = __ballot(enqueue);
-            if (enqueue) {
-                const unsigned q = qpos + (unsigned)__popcll(m & lt);
-                w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, closest);
-                w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(slot));
-                w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
-                w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, 0.0f);
-            }
+            const unsigned long long m = __ballot(enq);
+            if (enq) wf_store_record(w, qpos + (unsigned)__popcll(m & lt), mr, closest, slot);
             qpos += (unsigned)__popcll(m);
         }
-        if (lane == 0) w.qn[task] = qpos - base;
+        if (lane == 0) { w.live[task] = n; w.qn[task] = qpos - base; }
     }
-    const unsigned seg = wave_sum(n_seg);
-    if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
     if (STATS) {
         const unsigned c = wave_sum(n_culled);
         if (lane == 0 && c) atomicAdd(&counters->box_tests, 2ull * c);   // the root's two boxes were tested
     }
 }
 
-// Persistent BVH traversal of the queued rays of one mesh prim.  A wave pulls whole tasks (one atomic
-// each) and hands their rays to its lanes as they fall idle (ballot + prefix count, no atomics).
+// Scenes with several meshes: analytic prims [p0, mesh_prim) + preparation for mesh prim `mesh_prim`.
 template <bool STATS>
-__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, WfBuf w, unsigned* head,
-                                                      DeviceCounters* counters) {
+__global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, RenderMap map, unsigned n_local, int s0, int round, int par,
+                                                int p0, int mesh_prim, WfBuf w, DeviceCounters* counters) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned n_culled = 0;
+    for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
+        const unsigned base = task * w.T;
+        const unsigned n = w.live[task];
+        unsigned qpos = base;
+        for (unsigned j0 = 0; j0 < n; j0 += 64) {
+            const unsigned pos = base + j0 + lane;
+            bool enq = false;
+            MeshRay mr;
+            float closest = 0.0f;
+            if (j0 + lane < n) {
+                const float4 a = w.S0[par][pos], b = w.S1[par][pos];
+                const vec3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
+                closest = a.w;
+                int prim = __float_as_int(w.S2[par][pos].w), sub = w.S3[par][pos];
+                const int prim0 = prim;
+                const rng_ctx ctx = slot_ctx(pr, map, __float_as_uint(b.w), n_local, s0, round);
+                enq = wf_prepare<STATS>(sc, pr, p0, mesh_prim, mesh_prim, o, d, ctx, closest, prim, sub, mr, n_culled);
+                if (prim != prim0) {
+                    ((float*)&w.S0[par][pos])[3] = closest;
+                    ((float*)&w.S2[par][pos])[3] = __int_as_float(prim);
+                    w.S3[par][pos] = sub;
+                }
+            }
+            const unsigned long long m = __ballot(enq);
+            if (enq) wf_store_record(w, qpos + (unsigned)__popcll(m & lt), mr, closest, pos);
+            qpos += (unsigned)__popcll(m);
+        }
+        if (lane == 0) w.qn[task] = qpos - base;
+    }
+    if (STATS) {
+        const unsigned c = wave_sum(n_culled);
+        if (lane == 0 && c) atomicAdd(&counters->box_tests, 2ull * c);
+    }
+}
+
+// Persistent BVH traversal of the queued rays of one mesh prim.  A wave walks its tasks (strided static
+// ownership) and hands their rays to its lanes as they fall idle (ballot + prefix count, no atomics).
+template <bool STATS>
+__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w, unsigned* head,
+                                                      DeviceCounters* counters, int leaf_num) {
     __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
@@ -328,18 +395,21 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     bool has = false;
     unsigned cur_pos = 0, cur_end = 0;   // wave-uniform: unread rays of the wave's current task
     bool wave_done = false;              // wave-uniform: no task left
+    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned next_task = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
     MeshRay r;
     TravState ts;
     ts.cur = HRT_TRAV_DONE;
-    unsigned slot = 0;
+    unsigned pos = 0;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
     for (;;) {
         const unsigned long long need = __ballot(!has);
         if (need && !wave_done) {
             while (cur_pos >= cur_end && !wave_done) {
-                unsigned t = 0;
-                if (lane == 0) t = atomicAdd(head, 1u);
-                t = __shfl(t, 0, 64);
+                // tasks are owned statically, strided over the waves of the grid: no atomic at all (a global
+                // task counter costs n_tasks + n_waves single-address atomics per launch, ~0.2 ms each time)
+                const unsigned t = next_task;
+                next_task += n_waves;
                 if (t >= w.n_tasks) wave_done = true;
                 else { cur_pos = t * w.T; cur_end = cur_pos + w.qn[t]; }
             }
@@ -351,7 +421,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
                     r.tr.o = r.o; r.tr.sX = e2.x; r.tr.sY = e2.y; r.tr.sZ = e2.z; r.tr.kZ = __float_as_int(e2.w);
                     r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
                     r.ox = r.o.x * r.idx; r.oy = r.o.y * r.idy; r.oz = r.o.z * r.idz;
-                    slot = __float_as_uint(e1.w);
+                    pos = __float_as_uint(e1.w);
                     trav_init(ts, mesh, e0.w);
                     has = true;
                 }
@@ -362,9 +432,15 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             if (wave_done) break;
             continue;
         }
-        // while-while: walk inner nodes until every lane of the wave stands at a leaf (or is done), then
-        // test the leaves together; idle lanes are refilled at the top of the next round.
-        while (__ballot(has && trav_at_inner(ts))) {
+        // while-while with postponed leaves: walk inner nodes until at least leaf_num/64 of the wave's
+        // busy lanes stand at a leaf (waiting for ALL of them would run the loop at the pace of the slowest
+        // lane), then test the leaves together.  Lanes still at an inner node sit the leaf phase out; idle
+        // lanes are refilled at the top of the next round.
+        for (;;) {
+            const unsigned long long m_in = __ballot(has && trav_at_inner(ts));
+            if (!m_in) break;
+            const int n_leaf = __popcll(__ballot(has && trav_at_leaf(ts)));
+            if (n_leaf * 64 >= leaf_num * (n_leaf + __popcll(m_in))) break;
             if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
         }
         if (has) {
@@ -372,7 +448,11 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             if (ts.cur == HRT_TRAV_DONE) {
                 float t;
                 const int tri = trav_result(ts, t);
-                if (tri >= 0) { ((float*)&w.A[slot])[3] = t; w.H[slot] = make_int2(mesh_prim, tri); }
+                if (tri >= 0) {
+                    ((float*)&w.S0[par][pos])[3] = t;
+                    ((float*)&w.S2[par][pos])[3] = __int_as_float(mesh_prim);
+                    w.S3[par][pos] = tri;
+                }
                 has = false;
             }
         }
@@ -386,64 +466,77 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     }
 }
 
-// Remaining analytic prims [p0, n_prims), then main.cpp:46-76 for every live slot; the task's survivors are
-// compacted in place at the front of its list segment.
+// The rest of the segment (analytic prims behind the last mesh, main.cpp:46-76) for every live path, and,
+// for the survivors, the preparation of their next segment.  Survivors are written compacted, in order,
+// to the other state copy.
+#ifndef HRT_SHADE_WAVES
+#define HRT_SHADE_WAVES 1
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_wf_shade(DScene sc, hrt_params pr, RenderMap map, unsigned n_local, int s0, int round,
-                                                  int p0, WfBuf w, DeviceCounters* counters, int count_rays) {
+__global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hrt_params pr, RenderMap map, WfScene ws, unsigned n_local, int s0, int round,
+                                                  WfBuf w, DeviceCounters* counters) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned n_seg = 0;
+    const int par = round & 1, nxt = par ^ 1;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
+    stage_tables(sc, s_tables);
+    unsigned n_seg = 0, n_culled = 0;
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
     for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
         const unsigned base = task * w.T;
         const unsigned n = w.live[task];
-        unsigned out = base;
+        unsigned out = base, qpos = base;
         for (unsigned j0 = 0; j0 < n; j0 += 64) {
-            const unsigned j = j0 + lane;
+            const unsigned pos = base + j0 + lane;
+            float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+            int sub0 = -1;
+            if (j0 + lane < n) { a = w.S0[par][pos]; b = w.S1[par][pos]; c = w.S2[par][pos]; sub0 = w.S3[par][pos]; }
             bool alive = false;
+            PathState ps;
             unsigned slot = 0;
-            if (j < n) {
-                slot = round == 0 ? base + j : w.list[base + j];
+            rng_ctx ctx; ctx.seed_lo = 0; ctx.seed_hi = 0; ctx.pixel = 0; ctx.sample = 0; ctx.bounce = 0;
+            if (j0 + lane < n) {
                 n_seg++;
-                const float4 a = w.A[slot], b = w.B[slot], c = w.C[slot], dd = w.D[slot];
-                int2 h = w.H[slot];
-                PathState ps;
                 ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(b.x, b.y, b.z);
-                ps.atten = vec3(c.x, c.y, c.z); ps.result = vec3(dd.x, dd.y, dd.z); ps.bounce = round;
+                ps.atten = vec3(c.x, c.y, c.z); ps.result = vec3(0.0f); ps.bounce = round;
+                slot = __float_as_uint(b.w);
                 float closest = a.w;
-                const rng_ctx ctx = slot_ctx(pr, map, slot, n_local, s0, round);
-                prims_range_hit(sc, p0, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, h.x, h.y);
-                WorldHit wh; wh.prim = h.x; wh.sub = h.y; wh.t = closest;
+                int prim = __float_as_int(c.w), sub = sub0;
+                ctx = slot_ctx(pr, map, slot, n_local, s0, round);
+                prims_range_hit(sc, ws.rest, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
+                WorldHit wh; wh.prim = prim; wh.sub = sub; wh.t = closest;
                 const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
-                if (ended) {
-                    w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
-                } else {
-                    w.A[slot] = make_float4(ps.o.x, ps.o.y, ps.o.z, __builtin_huge_valf());
-                    w.B[slot] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f);
-                    w.C[slot] = make_float4(ps.atten.x, ps.atten.y, ps.atten.z, 0.0f);
-                    w.D[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
-                    w.H[slot] = make_int2(-1, -1);
-                    alive = true;
-                }
+                if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
+                else alive = true;
             }
-            // in-place compaction: every write lands at or below positions this wave has already read
-            const unsigned long long m = __ballot(alive);
-            if (alive) w.list[out + (unsigned)__popcll(m & lt)] = slot;
-            out += (unsigned)__popcll(m);
+            const unsigned long long ma = __ballot(alive);
+            bool enq = false;
+            MeshRay mr;
+            float closest = __builtin_huge_valf();
+            unsigned npos = 0;
+            if (alive) {
+                npos = out + (unsigned)__popcll(ma & lt);
+                int prim = -1, sub = -1;
+                ctx.bounce = (uint32_t)(round + 1);   // the next segment's draws (ConstantMedium::hit inside wf_prepare)
+                enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
+                wf_store_state(w, nxt, npos, ps, closest, slot, prim, sub);
+            }
+            out += (unsigned)__popcll(ma);
+            const unsigned long long me = __ballot(enq);
+            if (enq) wf_store_record(w, qpos + (unsigned)__popcll(me & lt), mr, closest, npos);
+            qpos += (unsigned)__popcll(me);
         }
-        if (lane == 0) w.live[task] = out - base;
+        if (lane == 0) { w.live[task] = out - base; w.qn[task] = qpos - base; }
     }
-    if (count_rays) {   // scenes without a mesh have no k_wf_pre to count the segments
-        const unsigned seg = wave_sum(n_seg);
-        if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
-    }
+    const unsigned seg = wave_sum(n_seg);
+    if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
     if (STATS) {
-        const unsigned mh = wave_sum(pc.mesh_hits), ev = wave_sum(pc.env_lookups);
+        const unsigned mh = wave_sum(pc.mesh_hits), ev = wave_sum(pc.env_lookups), c = wave_sum(n_culled);
         if (lane == 0) {
             if (mh) atomicAdd(&counters->mesh_hits, (unsigned long long)mh);
             if (ev) atomicAdd(&counters->env_lookups, (unsigned long long)ev);
+            if (c) atomicAdd(&counters->box_tests, 2ull * c);
         }
     }
 }
@@ -639,7 +732,7 @@ hrt_status launch_megakernel(hrt_scene* sc, const hrt_camera* cam, const hrt_par
 }
 
 size_t wf_max_slots() {
-    size_t cap = (size_t)48 << 20;                       // 48 Mi slots x 160 B = 7.5 GiB of the 288 GB
+    size_t cap = (size_t)48 << 20;                       // 48 Mi slots x 184 B = 8.6 GiB of the 288 GB
     if (const char* e = getenv("HRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) cap = (size_t)v; }
     return cap;
 }
@@ -653,18 +746,18 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     const size_t head_words = (size_t)depth * (n_mesh > 0 ? n_mesh : 1);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * sizeof(float4));
-    const size_t total = 9 * f4 + al(slots * sizeof(int2)) + al(slots * sizeof(unsigned)) + 2 * al(max_tasks * sizeof(unsigned)) +
-                         al(head_words * sizeof(unsigned));
+    const size_t i4 = al(slots * sizeof(int));
+    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) + al(head_words * sizeof(unsigned));   // 184 B per slot
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, total);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string("hipMalloc(wavefront workspace): ") + hipGetErrorString(e));
     char* p = (char*)base;
     auto take = [&](size_t bytes) { char* q = p; p += bytes; return q; };
-    w.buf.A = (float4*)take(f4); w.buf.B = (float4*)take(f4); w.buf.C = (float4*)take(f4); w.buf.D = (float4*)take(f4);
+    for (int k = 0; k < 2; ++k) {
+        w.buf.S0[k] = (float4*)take(f4); w.buf.S1[k] = (float4*)take(f4); w.buf.S2[k] = (float4*)take(f4); w.buf.S3[k] = (int*)take(i4);
+    }
     w.buf.E0 = (float4*)take(f4); w.buf.E1 = (float4*)take(f4); w.buf.E2 = (float4*)take(f4); w.buf.E3 = (float4*)take(f4);
     w.buf.rad = (float4*)take(f4);
-    w.buf.H = (int2*)take(al(slots * sizeof(int2)));
-    w.buf.list = (unsigned*)take(al(slots * sizeof(unsigned)));
     w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.heads = (unsigned*)take(al(head_words * sizeof(unsigned)));
@@ -672,7 +765,7 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     return HRT_OK;
 }
 
-// render() as the wavefront pipeline: see the comment above k_wf_gen.
+// render() as the wavefront pipeline: see the comment above struct WfBuf.
 hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
                             hipStream_t stream) {
     const unsigned n_local = (unsigned)map.rw * (unsigned)map.rh;
@@ -685,39 +778,47 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     hrt_status st = wf_reserve(sc, slots, D);
     if (st != HRT_OK) return st;
     WfBuf w = sc->wf.buf;
+    WfScene ws;
+    ws.has_mesh = n_mesh > 0;
+    ws.first_mesh = n_mesh > 0 ? sc->mesh_prims.front() : sc->n_prims;
+    ws.rest = n_mesh > 0 ? sc->mesh_prims.back() + 1 : sc->n_prims;
     const size_t head_words = (size_t)D * (n_mesh > 0 ? n_mesh : 1);
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
     const int ext_blocks = sc->n_cus * 4;
+    int leaf_num = 48;                                   // k_wf_ext: start the leaf phase when >= 48/64 of the busy lanes wait at a leaf
+    if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
+    leaf_num = std::min(64, std::max(1, leaf_num));      // >= 1: with no lane at a leaf the inner loop must go on
 
     for (int s0 = 0; s0 < pr->samples; s0 += chunk) {
         const int c = std::min(chunk, pr->samples - s0);
         const unsigned n_slots = n_local * (unsigned)c;
-        // task size: ~64 tasks per CU so the tail is short, between 256 and 4096 slots, a multiple of 64
+        // task size: ~64 tasks per CU so the tail is short, between 256 and 4096 positions, a multiple of 64
         size_t T = (n_slots / ((size_t)sc->n_cus * 64) + 63) & ~(size_t)63;
         T = std::min<size_t>(4096, std::max<size_t>(256, T));
         w.T = (unsigned)T;
         w.n_tasks = (unsigned)((n_slots + T - 1) / T);
-        const int dense = (int)std::min<size_t>((n_slots + 255) / 256, (size_t)sc->n_cus * 8);
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
         HIPCHK(hipMemsetAsync(w.heads, 0, head_words * sizeof(unsigned), stream));
-        hipLaunchKernelGGL(k_wf_gen, dim3(dense), dim3(256), 0, stream, *cam, *pr, map, n_local, s0, n_slots, w);
+        if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
+        else hipLaunchKernelGGL(k_wf_gen<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         for (int r = 0; r < D; ++r) {
-            int pb = 0;
+            const int par = r & 1;
             for (int m = 0; m < n_mesh; ++m) {
                 const int mp = sc->mesh_prims[m];
                 unsigned* head = w.heads + (size_t)r * n_mesh + m;
-                if (stats) hipLaunchKernelGGL(k_wf_pre<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, mp, mp, w, sc->d_counters);
-                else hipLaunchKernelGGL(k_wf_pre<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, mp, mp, w, sc->d_counters);
+                if (m > 0) {   // further meshes: analytic prims between the meshes + preparation
+                    const int p0 = sc->mesh_prims[m - 1] + 1;
+                    if (stats) hipLaunchKernelGGL(k_wf_pre<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
+                    else hipLaunchKernelGGL(k_wf_pre<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
+                }
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (timing) { st = get_event(sc, &ea); if (st != HRT_OK) return st; st = get_event(sc, &eb); if (st != HRT_OK) return st; HIPCHK(hipEventRecord(ea, stream)); }
-                if (stats) hipLaunchKernelGGL(k_wf_ext<true>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, w, head, sc->d_counters);
-                else hipLaunchKernelGGL(k_wf_ext<false>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, w, head, sc->d_counters);
+                if (stats) hipLaunchKernelGGL(k_wf_ext<true>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num);
+                else hipLaunchKernelGGL(k_wf_ext<false>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num);
                 if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
-                pb = mp + 1;
             }
-            const int count_rays = n_mesh == 0 ? 1 : 0;
-            if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, w, sc->d_counters, count_rays);
-            else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, pb, w, sc->d_counters, count_rays);
+            if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
+            else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
         }
         const int rblocks = (int)std::min<size_t>((n_local + 255) / 256, (size_t)sc->n_cus * 8);
         hipLaunchKernelGGL(k_wf_reduce, dim3(rblocks), dim3(256), 0, stream, w.rad, n_local, c, s0 == 0 ? 1 : 0, s0 + c >= pr->samples ? 1 : 0, pr->samples, d_out, sc->d_counters);
@@ -859,6 +960,8 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     sc->ds.texels_u8 = d_u8; sc->ds.texels_f32 = d_f32;
     sc->ds.n_prims = (int32_t)f->n_prims;
     sc->ds.background_tex = f->background_tex;
+    sc->ds.lprims = d_prims; sc->ds.lmats = d_mats; sc->ds.ltexs = d_texs; sc->ds.lmeshes = d_meshes;
+    sc->ds.n_mats = (int32_t)f->n_materials; sc->ds.n_texs = (int32_t)f->n_textures; sc->ds.n_meshes = (int32_t)f->n_meshes;
     sc->n_prims = (int)f->n_prims;
     for (uint32_t i = 0; i < f->n_prims; ++i)
         if (f->prims[i].kind == HRT_PRIM_MESH) sc->mesh_prims.push_back((int)i);
@@ -894,6 +997,7 @@ hrt_status hrt_render_stripes_device(hrt_scene* sc, const hrt_camera* cam, const
     map.rw = pr->width; map.rh = hrt_stripe_rows(pr->height, R, rank, G);
     map.tiles_x = (map.rw + 7) / 8;
     map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
+    map.m_rw = fastdiv_magic((uint32_t)map.rw); map.m_nl = fastdiv_magic((uint32_t)map.rw * (uint32_t)map.rh);
     return launch_pathtrace(sc, cam, pr, map, d_out, (hipStream_t)stream);
 }
 
@@ -934,6 +1038,7 @@ hrt_status hrt_render_tile(hrt_scene* sc, const hrt_camera* cam, const hrt_param
     map.mode = 0; map.x0 = tile.x0; map.y0 = tile.y0; map.rw = tile.w; map.rh = tile.h; map.R = 1; map.G = 1;
     map.tiles_x = (map.rw + 7) / 8;
     map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
+    map.m_rw = fastdiv_magic((uint32_t)map.rw); map.m_nl = fastdiv_magic((uint32_t)map.rw * (uint32_t)map.rh);
     st = launch_pathtrace(sc, cam, pr, map, d_out, nullptr);
     if (st == HRT_OK) {
         e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);

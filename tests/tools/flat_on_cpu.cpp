@@ -32,6 +32,8 @@ CpuScene* make(const hrt_flat_scene* f) {
     s->ds.tri_pos = (const float4*)s->pos.data(); s->ds.tri_attr = (const float4*)s->attr.data(); s->ds.tri_box = (const float4*)s->box.data();
     s->ds.texels_u8 = f->texels_u8; s->ds.texels_f32 = f->texels_f32;
     s->ds.n_prims = (int32_t)f->n_prims; s->ds.background_tex = f->background_tex;
+    s->ds.lprims = f->prims; s->ds.lmats = f->materials; s->ds.ltexs = f->textures; s->ds.lmeshes = f->meshes;
+    s->ds.n_mats = (int32_t)f->n_materials; s->ds.n_texs = (int32_t)f->n_textures; s->ds.n_meshes = (int32_t)f->n_meshes;
     return s;
 }
 }  // namespace
