@@ -1,0 +1,44 @@
+"""The CLI (hobbyraytracer_amd/bin/hobbyraytracer), drop-in for the reference executable (main.cpp:142-195):
+positional scene argument, default scene name in the cwd, console lines, exit code = Film::outputFilm()'s int
+(1 on success, Q-12), PNG equal to the oracle's film."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_renders_the_default_scene_and_matches_the_oracle(built, assets, scenes_dir, tmp_path):
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    # the reference resolves everything against the cwd (scene.cpp:294-296, mesh.cpp:56): stage a cwd like a user's
+    for f in ("teapot.obj", "old_hall_4k.hdr"):
+        shutil.copy(os.path.join(assets, f), tmp_path / f)
+    shutil.copy(os.path.join(scenes_dir, "teapot_scene.yaml"), tmp_path / "teapot_scene.yaml")
+    p = subprocess.run([api.CLI_PATH, "--size", "64x64", "--spp", "6", "--stats"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1, p.stderr                       # main.cpp:194 returns stb's 1 on success
+    out = p.stdout
+    assert "Loading scene: teapot_scene.yaml" in out and "Loaded mesh: teapot.obj" in out and "Indexed file: teapot.obj" in out
+    assert "Loaded scene: teapot_scene.yaml! (completed in" in out and "Pixels rendered: 4096/4096" in out and "Done! (completed in" in out
+    img = api.read_png(str(tmp_path / "teapot.png"))          # film.output of the YAML file
+    hs = api.HostScene(str(tmp_path / "teapot_scene.yaml"), str(tmp_path))
+    ref, _ = orc.World(hs.flat_ptr).render_tile(hs.camera(64, 64), api.default_params(64, 64, 6))
+    assert np.array_equal(img, orc.resolve_u8(ref))
+    # explicit scene path + fixed quirks + BMP fallback for an unknown suffix (film.cpp:73-78)
+    p = subprocess.run([api.CLI_PATH, "teapot_scene.yaml", "--size", "48x32", "--spp", "2", "--quirks", "fixed", "--out", "x.foo", "--seed", "7"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and "File type not supported, generating bitmap!" in p.stdout
+    assert open(tmp_path / "x.foo", "rb").read(2) == b"BM"
+
+
+def test_cli_make_assets(built, tmp_path):
+    from hobbyraytracer_amd import api
+    p = subprocess.run([api.CLI_PATH, "--make-assets", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for f in ("teapot.obj", "marble_bust_01.obj", "old_hall_4k.hdr"):
+        assert os.path.getsize(tmp_path / f) > 1000
+    env = api.read_hdr(str(tmp_path / "old_hall_4k.hdr"))
+    assert env.shape == (2048, 4096, 3) and 49 < env.max() <= 50.5     # windows "up to ~50.0" 
