@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--megakernel", action="store_true", help="time the persistent-lanes megakernel instead of the wavefront pipeline")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; 'gloo' only to rehearse N > 1 "
+                    "with all ranks sharing one GPU, where RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,10 +91,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    if args.backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()     # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- inputs: procedural assets + scene load + flatten + upload (all untimed)
     tmp = tempfile.mkdtemp(prefix=f"hrt_bench_r{rank}_")

@@ -156,28 +156,19 @@ HRT_HD float atan_core(float x) {  // x >= 0
 }
 }  // namespace detail
 
-HRT_HD float gsin(float x) {
+// sin and cos of one angle: one range reduction, each polynomial evaluated once, quadrant handled by
+// selects (no per-lane switch: on the GPU a `switch (q & 3)` makes a wave execute all four cases).
+// Same operations and results as the textbook form  q&3: 0 -> (s, c)  1 -> (c, -s)  2 -> (-s, -c)  3 -> (-c, s).
+HRT_HD void gsincos(float x, float& s_out, float& c_out) {
     int q; float r = detail::reduce_pio2(x, q);
-    float s;
-    switch (q & 3) {
-        case 0: s = detail::sin_poly(r); break;
-        case 1: s = detail::cos_poly(r); break;
-        case 2: s = -detail::sin_poly(r); break;
-        default: s = -detail::cos_poly(r); break;
-    }
-    return s;
+    const float s = detail::sin_poly(r), c = detail::cos_poly(r);
+    const bool swap = (q & 1) != 0;
+    const float ss = swap ? c : s, cc = swap ? s : c;
+    s_out = (q & 2) ? -ss : ss;
+    c_out = (((q + 1) & 2) != 0) ? -cc : cc;
 }
-HRT_HD float gcos(float x) {
-    int q; float r = detail::reduce_pio2(x, q);
-    float c;
-    switch (q & 3) {
-        case 0: c = detail::cos_poly(r); break;
-        case 1: c = -detail::sin_poly(r); break;
-        case 2: c = -detail::cos_poly(r); break;
-        default: c = detail::sin_poly(r); break;
-    }
-    return c;
-}
+HRT_HD float gsin(float x) { float s, c; gsincos(x, s, c); return s; }
+HRT_HD float gcos(float x) { float s, c; gsincos(x, s, c); return c; }
 HRT_HD float gasin(float x) {
     float a = fabsf(x);
     float r;

@@ -76,10 +76,12 @@ HRT_HD float linear_rand(uint32_t u, float mn, float mx) { return u01(u) * (mx -
 HRT_HD vec3 spherical_rand(uint32_t u_theta, uint32_t u_z) {
     float theta = linear_rand(u_theta, 0.0f, 6.283185307179586476925286766559f);
     float phi = gacos(linear_rand(u_z, -1.0f, 1.0f));
-    float sp = gsin(phi);
-    float x = sp * gcos(theta);
-    float y = sp * gsin(theta);
-    float z = gcos(phi);
+    float sp, cp, st, ct;
+    gsincos(phi, sp, cp);
+    gsincos(theta, st, ct);
+    float x = sp * ct;
+    float y = sp * st;
+    float z = cp;
     return vec3(x, y, z);
 }
 
