@@ -335,7 +335,13 @@ __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks) {
     MeshRay r;
     r.o = o; r.d = d;
     r.tr = tri_ray_setup(o, d, quirks);
-    r.idx = 1.0f / d.x; r.idy = 1.0f / d.y; r.idz = 1.0f / d.z;
+    // A zero (or denormal) direction component must stay usable: 1/0 = inf would turn o * (1/d) into inf and
+    // the fused b * (1/d) - o * (1/d) into NaN, culling everything, whereas the reference's division-based slab
+    // test (aabb.h:28-31) yields -inf / +inf and passes a box whose slab contains the origin.  A huge finite
+    // reciprocal keeps the signs of (b - o) / d, which is all the slab comparison needs.
+    r.idx = fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : 1.0f / d.x;
+    r.idy = fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : 1.0f / d.y;
+    r.idz = fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : 1.0f / d.z;
     r.ox = o.x * r.idx; r.oy = o.y * r.idy; r.oz = o.z * r.idz;
     return r;
 }

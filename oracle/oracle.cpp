@@ -904,6 +904,33 @@ int oracle_closest_hit(oracle_world* h, const hrt_params* pr, int64_t n, const f
     return 0;
 }
 
+// Debug aid for the parity tests: the segments of ONE path (pixel pIdx, sample s): per segment 6 floats
+// (ray o, d) and 3 values (prim, tri, t).  Returns the number of segments written (<= max_seg).
+int oracle_trace_path(oracle_world* h, const hrt_camera* cam, const hrt_params* pr, int pIdx, int s, int max_seg, float* rays, float* hits) {
+    g_quirks = pr->quirks;
+    g_ctx.seed_lo = pr->seed_lo; g_ctx.seed_hi = pr->seed_hi; g_ctx.pixel = (uint32_t)pIdx; g_ctx.sample = (uint32_t)s; g_ctx.bounce = 0;
+    const int W = pr->width, H = pr->height;
+    int x = pIdx % W, y = H - pIdx / W;
+    u32x4 j = rng_draw(g_ctx, RNG_JITTER, 0);
+    float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (W - 1);
+    float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (H - 1);
+    ray r = getRay(cam, u, v);
+    int n = 0;
+    for (int i = 0; i < pr->max_depth && n < max_seg; ++i) {
+        g_ctx.bounce = (uint32_t)i;
+        hitRecord rec; int prim;
+        bool hit = world_hit(*h->w, r, pr->t_min, std::numeric_limits<float>::infinity(), rec, prim);
+        float* q = rays + 6 * n; q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.dir.x; q[4] = r.dir.y; q[5] = r.dir.z;
+        float* hh = hits + 3 * n; hh[0] = (float)prim; hh[1] = hit ? (float)rec.tri : -1.0f; hh[2] = hit ? rec.t : 0.0f;
+        ++n;
+        if (!hit) break;
+        ray scattered; vec3 attenuation;
+        if (!rec.matPtr->scatter(r, rec, attenuation, scattered)) break;
+        r = scattered;
+    }
+    return n;
+}
+
 // Film::tonemap + Film::writeColour
 void oracle_resolve_u8(const float* rgb, int64_t n_pixels, uint8_t* out) {
     for (int64_t i = 0; i < n_pixels; ++i) {

@@ -92,6 +92,17 @@ class World:
         return out
 
 
+_lib.oracle_trace_path.argtypes = [_vp, C.POINTER(api.Camera), C.POINTER(api.Params), C.c_int, C.c_int, C.c_int, _fp, _fp]
+
+
+def trace_path(world, cam, params, pidx, sample, max_seg=64):
+    """Debug aid: (rays (n,6), hits (n,3) = prim, tri, t) of one path."""
+    rays = np.zeros((max_seg, 6), np.float32)
+    hits = np.zeros((max_seg, 3), np.float32)
+    n = _lib.oracle_trace_path(world._h, C.byref(cam), C.byref(params), pidx, sample, max_seg, _p(rays), _p(hits))
+    return rays[:n], hits[:n]
+
+
 def resolve_u8(rgb):
     a = _f32(rgb)
     out = np.empty(a.shape, dtype=np.uint8)

@@ -156,3 +156,44 @@ def test_closest_hit_flat_equals_oracle_with_self_hits(built, assets, scenes_dir
     hit = c["prim"] >= 0
     for f in ("t", "p", "normal", "u", "v"):
         assert np.array_equal(g[f][hit].view(np.uint32), c[f][hit].view(np.uint32)), f
+
+
+def test_axis_aligned_rays_zero_direction_components(built, assets, scenes_dir, tools):
+    """Rays with one or two direction components EXACTLY zero (camera rays of the centre row / column cancel to
+    d.y == 0 about ten times per 1024x1024 frame): the reference's division-based slab test (aabb.h:28-31) copes
+    with +-inf; the flattened traversal's reciprocal-based culling must give the same hits."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    r = np.random.default_rng(33)
+    for scene in ("teapot_scene.yaml", "shiny_teapot.yaml"):
+        hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
+        world, flat = orc.World(hs.flat_ptr), FlatCpu(hs.flat_ptr)
+        n = 60000
+        o = r.uniform([-2.2, 0.2, 3.0], [2.2, 3.2, 9.0], (n, 3)).astype(np.float32)
+        d = (r.uniform([-1.5, 0.5, -1.0], [1.5, 3.0, 1.0], (n, 3)) - o).astype(np.float32)
+        which = r.integers(0, 6, n)
+        d[which == 0, 0] = 0.0
+        d[which == 1, 1] = 0.0
+        d[which == 2, 2] = 0.0                       # parallel to the view plane: mostly misses, must not crash or differ
+        d[which == 3, 0] = 0.0; d[which == 3, 1] = 0.0
+        d[which == 4, 1] = -0.0
+        d[which == 5, 0] = -0.0; d[which == 5, 1] = 0.0
+        for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+            p = api.default_params(8, 8, 1, quirks=q)
+            g, c = flat.closest_hit(p, o, d), world.closest_hit(p, o, d)
+            assert (c["tri"] >= 0).sum() > 500       # (under Q-1 the instanced teapot loses most depth comparisons)
+            # Q-4 (shear axis from the ORIGIN) with d == 0 on that axis: triangle.cpp:81-83 divides by zero, every
+            # comparison of triangle.cpp:98-109 is false on NaN, so the reference ACCEPTS a hit with t = NaN; which
+            # triangle ends up in the record then depends on its tree order (the pixel becomes NaN and film.cpp:35-37
+            # scrubs it to black either way).  Required there: both sides report such a NaN hit.
+            # Whether such a NaN hit exists at all depends on which of the REFERENCE tree's boxes the ray reaches
+            # (DESIGN.md "Residual differences"); it is confined to these rays, rare, and absent with quirks=fixed.
+            nan = np.isnan(c["t"]) | np.isnan(g["t"])
+            if q == api.QUIRKS_FIXED:
+                assert not nan.any()
+            else:
+                assert nan.mean() < 0.03 and (np.isnan(c["t"]) & np.isnan(g["t"])).sum() >= 0.8 * nan.sum()
+            ok = ~nan
+            assert np.array_equal(g["prim"][ok], c["prim"][ok]) and np.array_equal(g["tri"][ok], c["tri"][ok]), (scene, q)
+            hit = (c["prim"] >= 0) & ok
+            assert np.array_equal(g["t"][hit].view(np.uint32), c["t"][hit].view(np.uint32))

@@ -137,3 +137,68 @@ def test_scene_validation_refuses_malformed_input(built, assets, scenes_dir):
         api.DeviceScene(hs.flat_ptr, 0).render_tile(hs.camera(8, 8), api.default_params(8, 8, 1), (4, 4, 8, 8))   # tile outside the film
     with pytest.raises(api.HrtError):
         api.DeviceScene(hs.flat_ptr, 77)                                                                       # no such device
+
+
+def test_device_pointer_stream_api_with_torch(built, assets, scenes_dir):
+    """hrt_render_stripes_device / hrt_resolve_u8_device on a caller-owned device buffer and HIP stream (the form
+    bench.py and a one-process-per-GPU host use): results equal the host-buffer entry points bit for bit."""
+    import torch
+    from hobbyraytracer_amd import api, tiles
+    hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    W, H, spp, R = 96, 72, 6, 8
+    cam, p = hs.camera(W, H), api.default_params(W, H, spp)
+    full, _ = dev.render_tile(cam, p)
+    stream = torch.cuda.Stream()
+    film = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    with torch.cuda.stream(stream):
+        for G in (1, 3):
+            for rank in range(G):
+                layout = tiles.StripeLayout(H, W, R, G)
+                tile = torch.full((layout.max_rows, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+                dev.render_stripes_device(cam, p, R, rank, G, tile.data_ptr(), stream.cuda_stream)
+                rows = torch.as_tensor(layout.row_indices(rank), device="cuda")
+                film[rows] = tile[:len(rows)]
+            stream.synchronize()
+            assert np.array_equal(film.cpu().numpy().view(np.uint32), full.view(np.uint32)), f"G={G}"
+        u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        dev.resolve_u8_device(film.data_ptr(), W * H, u8.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+    assert np.array_equal(u8.cpu().numpy(), dev.resolve_u8(full))
+    st = dev.stats()
+    assert st.launches == 4 and st.samples == W * H * spp * 2      # 1 + 3 stripe launches cover the film twice
+    dev.close()
+
+
+FULL_SIZE = [  # BASELINE.json configs at their full FILM sizes; spp reduced where the config's spp would only repeat the same code path
+    ("cornell_box.yaml", 640, 640, 256, "C2: 640x640x256, analytic primitives only"),
+    ("teapot_scene.yaml", 1024, 1024, 256, "C3: 1024x1024x256 (sample-chunked: 268 M slots > the 48 M slot budget)"),
+    ("shiny_teapot.yaml", 1920, 1080, 16, "C4 film 1920x1080 (512 spp in BASELINE; 16 here)"),
+    ("bust_scene.yaml", 2048, 2048, 4, "C5 film 2048x2048 (1024 spp in BASELINE; 4 here)"),
+]
+
+
+@pytest.mark.parametrize("scene,W,H,spp,what", FULL_SIZE)
+def test_full_size_properties(built, assets, scenes_dir, scene, W, H, spp, what):
+    """Size-independent properties at BASELINE's film sizes: exact sample count, finite non-negative film, a 32x8
+    block equal to the oracle bit for bit, and row-stripe rendering of two ranks equal to the full frame."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    quirks = api.QUIRKS_FIXED if scene == "teapot_scene.yaml" else api.QUIRKS_REFERENCE   # C3 = fixed quirks (SURVEY §8d)
+    hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    cam, p = hs.camera(W, H), api.default_params(W, H, spp, quirks=quirks)
+    full, st = dev.render_tile(cam, p)
+    assert st.samples == W * H * spp and st.rays >= st.samples
+    finite = np.isfinite(full)
+    assert finite.mean() > 0.9999 and (full[finite] >= 0).all()    # a NaN sample poisons only its own pixel (film.cpp:35-37 scrubs it)
+    x0, y0 = W // 2 - 16, H // 2
+    ref, _ = orc.World(hs.flat_ptr).render_tile(cam, p, (x0, y0, 32, 8))
+    assert np.array_equal(full[y0:y0 + 8, x0:x0 + 32].view(np.uint32), ref.view(np.uint32)), what
+    if W * H * spp <= 50_000_000:
+        out = np.zeros_like(full)
+        for rank in range(2):
+            part, _ = dev.render_stripes(cam, p, 8, rank, 2)
+            out[api.stripe_row_indices(H, 8, rank, 2)] = part
+        assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
+    dev.close()
