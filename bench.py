@@ -105,6 +105,8 @@ def main():
     tmp = tempfile.mkdtemp(prefix=f"hrt_bench_r{rank}_")
     api.write_teapot_obj(os.path.join(tmp, "teapot.obj"), 1.0)
     api.write_hall_hdr(os.path.join(tmp, "old_hall_4k.hdr"), 4096, 2048)
+    if "bust" in args.scene:
+        api.write_bust_obj(os.path.join(tmp, "marble_bust_01.obj"), 1.0)   # ~100k triangles (config C5)
     hs = api.HostScene(os.path.join(ROOT, "tests", "golden", "scenes", args.scene), tmp)
     W, H, spp = args.width, args.height, args.spp
     cam = hs.camera(W, H)

@@ -445,7 +445,19 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
         const float t = ev.tScaled * invDet;
         if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
         const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
-        if (!accept_box(bmn, bmx, r.o, r.d, t_min, ts.closest)) continue;
+        // accept_box costs six IEEE divisions and almost always passes.  Shortcut with the SAME outcome: if t is
+        // clear of t_min, closest >= t, and the hit point o + t d lies inside the box by a margin far above the
+        // rounding of (box - o) / d, then on every axis the slab interval strictly contains t, so after clipping
+        // to [t_min, closest] the interval is non-empty and aabb.h:35 cannot reject.  Anything closer to a face,
+        // t near t_min, or non-finite takes the exact test.
+        {
+            const float hx = r.o.x + t * r.d.x, hy = r.o.y + t * r.d.y, hz = r.o.z + t * r.d.z;
+            const float mgx = 1e-4f * (1.0f + fabsf(hx) + fabsf(r.o.x)), mgy = 1e-4f * (1.0f + fabsf(hy) + fabsf(r.o.y)),
+                        mgz = 1e-4f * (1.0f + fabsf(hz) + fabsf(r.o.z));
+            const bool inside = t > 1.001f * t_min && ts.closest >= t && hx - bmn.x > mgx && bmx.x - hx > mgx && hy - bmn.y > mgy &&
+                                bmx.y - hy > mgy && hz - bmn.z > mgz && bmx.z - hz > mgz;
+            if (!inside && !accept_box(bmn, bmx, r.o, r.d, t_min, ts.closest)) continue;
+        }
         if (t < t_min) {
             const uint32_t ord = (uint32_t)__float_as_int(bmn.w);
             bool take;

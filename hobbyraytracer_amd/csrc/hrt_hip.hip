@@ -784,7 +784,9 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     ws.rest = n_mesh > 0 ? sc->mesh_prims.back() + 1 : sc->n_prims;
     const size_t head_words = (size_t)D * (n_mesh > 0 ? n_mesh : 1);
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
-    const int ext_blocks = sc->n_cus * 4;
+    int ext_per_cu = 4;                                  // k_wf_ext blocks per CU (32 KB of LDS stacks each)
+    if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu = std::min(5, std::max(1, atoi(e)));
+    const int ext_blocks = sc->n_cus * ext_per_cu;
     int leaf_num = 48;                                   // k_wf_ext: start the leaf phase when >= 48/64 of the busy lanes wait at a leaf
     if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
     leaf_num = std::min(64, std::max(1, leaf_num));      // >= 1: with no lane at a leaf the inner loop must go on

@@ -12,7 +12,8 @@ for r in csv.DictReader(open(f)):
     n=r["Name"]
     if "k_wf" in n or "k_pathtrace" in n:
         ms=float(r["TotalDurationNs"])/1e6
-        if "<true>" not in n:
-            print("  %-22s calls %5s  %8.2f ms/frame"%(n.split("::")[-1].split("(")[0], r["Calls"], ms/3.0)); tot+=ms/3.0
+        if "<true>" not in n:   # 1 warmup + 3 timed frames run these kernels
+            short=n.split("(")[0].split("::")[-1]
+            print("  %-22s calls %5s  %8.2f ms/frame"%(short, r["Calls"], ms/4.0)); tot+=ms/4.0
 print("$tag: sum %.2f ms/frame"%tot)
 PY
