@@ -15,7 +15,9 @@
 
 namespace hrt {
 
+#ifndef HRT_STACK_DEPTH
 #define HRT_STACK_DEPTH 32
+#endif
 #define HRT_BLOCK 256
 
 struct DScene {
@@ -23,7 +25,8 @@ struct DScene {
     const hrt_material* mats;
     const hrt_texture* texs;
     const hrt_mesh* meshes;
-    const float4* nodes;     // 4 x float4 per node (hrt_bvh_node)
+    const uint4* qnodes;     // 2 x uint4 per node: 16-bit grid culling record (hrt_pack.h pack_nodes)
+    const float4* grids;     // 2 x float4 per mesh: grid origin.xyz_, step.xyz_
     const float4* tri_pos;   // 3 x float4 per triangle: v0.xyz_, v1.xyz_, v2.xyz_
     const float4* tri_attr;  // 4 x float4 per triangle: n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y _
     const float4* tri_box;   // 2 x float4 per triangle: reference leaf-level box (min.xyz_, max.xyz_)
@@ -42,6 +45,19 @@ struct DScene {
     const hrt_mesh* lmeshes;
     int32_t n_mats, n_texs, n_meshes;
 };
+
+// Wave-uniform walks over the small scene tables (the world-list loop, the mesh prim's wrapper chain) must be
+// SCALAR loads.  Through a plain global pointer the compiler may not scalarise them in kernels that also store
+// (the scalar cache is not coherent with vector stores), and each field then costs a full vector-memory round
+// trip -- measured: 41 % of k_wf_shade.  The tables are never written by a kernel, so view them through the
+// constant address space, whose loads are invariant by definition (s_load_*).  Host builds: plain pointers.
+#if defined(__HIPCC__)
+#define HRT_CONST_AS __attribute__((address_space(4)))
+template <class T> __device__ inline const HRT_CONST_AS T* uniform_table(const T* p) { return (const HRT_CONST_AS T*)p; }
+#else
+#define HRT_CONST_AS
+template <class T> inline const T* uniform_table(const T* p) { return p; }
+#endif
 
 #define HRT_TABLE_LDS_BYTES 12288
 #if defined(__HIPCC__)
@@ -84,7 +100,8 @@ __device__ inline void set_face_normal(DRec& rec, vec3 rdir, vec3 outward) {  //
 
 // ------------------------------------------------------------------ wrappers (ray side)
 // translate.cpp:9, scale.cpp:13-16, rotateQuat.cpp:47-52, rotateY.cpp:46-54
-__device__ inline void xf_apply(const hrt_xform& x, vec3& o, vec3& d, uint32_t quirks) {
+template <class XF>
+__device__ inline void xf_apply(const XF& x, vec3& o, vec3& d, uint32_t quirks) {
     if (x.kind == HRT_XF_TRANSLATE) {
         o = o - vec3(x.v[0], x.v[1], x.v[2]);
     } else if (x.kind == HRT_XF_SCALE) {
@@ -131,7 +148,8 @@ __device__ inline void xf_unapply(const hrt_xform& x, DRec& rec, vec3 ldir) {
 // ------------------------------------------------------------------ analytic primitives
 // aarect.h:12-39 / 59-86 / 106-133.  `axis` = the constant axis (0:YZ, 1:XZ, 2:XY).
 // p = a0,a1,b0,b1,k in the reference's member order.
-__device__ inline bool rect_hit(int axis, const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
+template <class P>
+__device__ inline bool rect_hit(int axis, P p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
     float ok, dk, oa, da, ob, db;
     if (axis == 0) { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
     else if (axis == 1) { ok = o.y; dk = d.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
@@ -161,7 +179,8 @@ __device__ inline void rect_rec(int axis, const float* p, vec3 o, vec3 d, float 
 __device__ inline int rect_axis(int kind) { return kind == HRT_PRIM_YZ_RECT ? 0 : (kind == HRT_PRIM_XZ_RECT ? 1 : 2); }
 
 // sphere.cpp:20-36
-__device__ inline bool sphere_hit(const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
+template <class P>
+__device__ inline bool sphere_hit(P p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
     vec3 center(p[0], p[1], p[2]);
     float radius = p[3];
     vec3 oc = o - center;
@@ -194,13 +213,15 @@ __device__ inline void sphere_rec(const float* p, vec3 o, vec3 d, float t, DRec&
 }
 
 // box.h:27-55: six rects in constructBox order, HittableList::hit semantics.
-__device__ inline void box_side(const float* p, int side, int& axis, float* rp) {
+template <class P>
+__device__ inline void box_side(P p, int side, int& axis, float* rp) {
     // p = min.xyz, max.xyz
     if (side < 2) { axis = 2; rp[0] = p[0]; rp[1] = p[3]; rp[2] = p[1]; rp[3] = p[4]; rp[4] = side == 0 ? p[5] : p[2]; }
     else if (side < 4) { axis = 1; rp[0] = p[0]; rp[1] = p[3]; rp[2] = p[2]; rp[3] = p[5]; rp[4] = side == 2 ? p[4] : p[1]; }
     else { axis = 0; rp[0] = p[1]; rp[1] = p[4]; rp[2] = p[2]; rp[3] = p[5]; rp[4] = side == 4 ? p[3] : p[0]; }
 }
-__device__ inline bool box_hit(const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t_out, int& side_out) {
+template <class P>
+__device__ inline bool box_hit(P p, vec3 o, vec3 d, float t_min, float t_max, float& t_out, int& side_out) {
     bool any = false;
     float closest = t_max;
 #pragma unroll
@@ -219,13 +240,15 @@ __device__ inline void box_rec(const float* p, vec3 o, vec3 d, float t, int side
     rect_rec(axis, rp, o, d, t, rec);
 }
 
-__device__ inline bool boundary_hit(int kind, const float* p, vec3 o, vec3 d, float t_min, float t_max, float& t) {
+template <class P>
+__device__ inline bool boundary_hit(int kind, P p, vec3 o, vec3 d, float t_min, float t_max, float& t) {
     int side;
     if (kind == HRT_PRIM_SPHERE) return sphere_hit(p, o, d, t_min, t_max, t);
     return box_hit(p, o, d, t_min, t_max, t, side);
 }
 // constantMedium.cpp:4-38
-__device__ inline bool medium_hit(const hrt_prim& pr, uint32_t prim_index, vec3 o, vec3 d, float t_min, float t_max,
+template <class PR>
+__device__ inline bool medium_hit(const PR& pr, uint32_t prim_index, vec3 o, vec3 d, float t_min, float t_max,
                                   const rng_ctx& ctx, float& t_out) {
     const float INF = __builtin_huge_valf();
     float t1, t2;
@@ -328,10 +351,16 @@ __device__ inline bool accept_box(float4 bmn, float4 bmx, vec3 o, vec3 d, float 
 struct MeshRay {          // a ray in mesh space plus its per-ray constants
     vec3 o, d;
     TriRay tr;            // exact-arithmetic constants of the triangle test
-    float idx, idy, idz;  // culling-only constants (free to differ from the reference: see header)
+    float idx, idy, idz;  // culling-only constants (free to differ from the reference: see header): 1/d,
+    float gx, gy, gz;     // and the slab test in the mesh's node-grid coordinates: t = q * g - o_ (q = 16-bit grid index)
     float ox, oy, oz;
 };
-__device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks) {
+// box = origin + q * step  =>  t = (box - o) / d = q * (step / d) - (o - origin) / d
+__device__ inline void mesh_ray_grid(MeshRay& r, float4 origin, float4 step) {
+    r.gx = r.idx * step.x; r.gy = r.idy * step.y; r.gz = r.idz * step.z;
+    r.ox = (r.o.x - origin.x) * r.idx; r.oy = (r.o.y - origin.y) * r.idy; r.oz = (r.o.z - origin.z) * r.idz;
+}
+__device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4 origin, float4 step) {
     MeshRay r;
     r.o = o; r.d = d;
     r.tr = tri_ray_setup(o, d, quirks);
@@ -342,7 +371,7 @@ __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks) {
     r.idx = fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : 1.0f / d.x;
     r.idy = fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : 1.0f / d.y;
     r.idz = fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : 1.0f / d.z;
-    r.ox = o.x * r.idx; r.oy = o.y * r.idy; r.oz = o.z * r.idz;
+    mesh_ray_grid(r, origin, step);
     return r;
 }
 #define HRT_TRAV_DONE 0x7fffffff
@@ -362,7 +391,8 @@ struct TravState {
     int sp;
     int cur;              // node index (>= 0), leaf code (< 0) or HRT_TRAV_DONE
 };
-__device__ inline void trav_init(TravState& ts, const hrt_mesh& mesh, float t_max) {
+template <class M>
+__device__ inline void trav_init(TravState& ts, const M& mesh, float t_max) {
     ts.closest = t_max; ts.best = -1;
     ts.selfhit = false; ts.self_order = 0xffffffffu; ts.self_tri = -1; ts.self_t = 0.0f;
     ts.sp = 0;
@@ -376,17 +406,17 @@ __device__ inline bool trav_at_inner(const TravState& ts) { return (unsigned)ts.
 __device__ inline bool trav_at_leaf(const TravState& ts) { return ts.cur < 0; }
 __device__ inline float trav_t_lo(float t_min, uint32_t quirks) { return (quirks & HRT_Q2_TRI_NO_TMIN) ? 0.0f : t_min; }
 
-// Slab test of BOTH child boxes of one 64-byte node against [t_lo, t_hi] (culling only).
-__device__ inline void node_test(const float4& n0, const float4& n1, const float4& n2, const MeshRay& r, float t_lo, float t_hi,
+// Slab test of BOTH child boxes of one 32-byte node against [t_lo, t_hi] (culling only).
+__device__ inline void node_test(const uint4& A, const uint4& B, const MeshRay& r, float t_lo, float t_hi,
                                  float& tn0, bool& h0, float& tn1, bool& h1) {
-    float a0 = fmaf(n0.x, r.idx, -r.ox), a1 = fmaf(n0.y, r.idx, -r.ox);
-    float b0 = fmaf(n0.z, r.idy, -r.oy), b1 = fmaf(n0.w, r.idy, -r.oy);
-    float c0 = fmaf(n2.x, r.idz, -r.oz), c1 = fmaf(n2.y, r.idz, -r.oz);
+    float a0 = fmaf((float)(A.x & 0xffffu), r.gx, -r.ox), a1 = fmaf((float)(A.x >> 16), r.gx, -r.ox);
+    float b0 = fmaf((float)(A.y & 0xffffu), r.gy, -r.oy), b1 = fmaf((float)(A.y >> 16), r.gy, -r.oy);
+    float c0 = fmaf((float)(A.z & 0xffffu), r.gz, -r.oz), c1 = fmaf((float)(A.z >> 16), r.gz, -r.oz);
     tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_lo));
     float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), t_hi));
-    float e0 = fmaf(n1.x, r.idx, -r.ox), e1 = fmaf(n1.y, r.idx, -r.ox);
-    float f0 = fmaf(n1.z, r.idy, -r.oy), f1 = fmaf(n1.w, r.idy, -r.oy);
-    float g0 = fmaf(n2.z, r.idz, -r.oz), g1 = fmaf(n2.w, r.idz, -r.oz);
+    float e0 = fmaf((float)(B.x & 0xffffu), r.gx, -r.ox), e1 = fmaf((float)(B.x >> 16), r.gx, -r.ox);
+    float f0 = fmaf((float)(B.y & 0xffffu), r.gy, -r.oy), f1 = fmaf((float)(B.y >> 16), r.gy, -r.oy);
+    float g0 = fmaf((float)(B.z & 0xffffu), r.gz, -r.oz), g1 = fmaf((float)(B.z >> 16), r.gz, -r.oz);
     tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_lo));
     float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), t_hi));
     h0 = tn0 <= tf0;
@@ -394,27 +424,34 @@ __device__ inline void node_test(const float4& n0, const float4& n1, const float
 }
 // The wavefront pipeline's root filter: would the first traversal step find any child of the root?
 // (Exactly the test trav_inner performs on node 0, so filtering changes no result.)
-__device__ inline bool root_may_hit(const DScene& sc, const hrt_mesh& mesh, const MeshRay& r, float t_lo, float t_hi) {
+template <class M>
+__device__ inline bool root_may_hit(const DScene& sc, const M& mesh, const MeshRay& r, float t_lo, float t_hi) {
     if (mesh.node_count == 0) return false;
-    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    const HRT_CONST_AS uint32_t* n = uniform_table((const uint32_t*)sc.qnodes) + 8ull * mesh.node_first;   // wave-uniform
+    uint4 A, B;
+    A.x = n[0]; A.y = n[1]; A.z = n[2]; A.w = n[3]; B.x = n[4]; B.y = n[5]; B.z = n[6]; B.w = n[7];
     float tn0, tn1; bool h0, h1;
-    node_test(nodes[0], nodes[1], nodes[2], r, t_lo, t_hi, tn0, h0, tn1, h1);
+    node_test(A, B, r, t_lo, t_hi, tn0, h0, tn1, h1);
     return h0 || h1;
+}
+// grid origin / step of mesh `mi` (wave-uniform)
+__device__ inline void mesh_grid(const DScene& sc, int mi, float4& origin, float4& step) {
+    const HRT_CONST_AS float* g = uniform_table((const float*)sc.grids) + 8 * mi;
+    origin.x = g[0]; origin.y = g[1]; origin.z = g[2]; origin.w = 0.0f;
+    step.x = g[4]; step.y = g[5]; step.z = g[6]; step.w = 0.0f;
 }
 
 // One inner-node step: tests both children of node ts.cur, descends / pushes / pops.
 template <bool STATS>
-__device__ inline void trav_inner(const float4* __restrict__ nodes, const MeshRay& r, TravState& ts, float t_lo, int* stack,
+__device__ inline void trav_inner(const uint4* __restrict__ nodes, const MeshRay& r, TravState& ts, float t_lo, int* stack,
                                   DCounters& cnt) {
     const int cur = ts.cur;
-    const float4 n0 = nodes[4 * cur + 0];
-    const float4 n1 = nodes[4 * cur + 1];
-    const float4 n2 = nodes[4 * cur + 2];
-    const float4 n3 = nodes[4 * cur + 3];
+    const uint4 A = nodes[2 * cur + 0];
+    const uint4 B = nodes[2 * cur + 1];
     if (STATS) cnt.box_tests += 2;
     float tn0, tn1; bool h0, h1;
-    node_test(n0, n1, n2, r, t_lo, ts.closest, tn0, h0, tn1, h1);
-    const int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
+    node_test(A, B, r, t_lo, ts.closest, tn0, h0, tn1, h1);
+    const int ch0 = (int)A.w, ch1 = (int)B.w;
     if (h0 && h1) {
         const bool swap = tn1 < tn0;
         const int nearc = swap ? ch1 : ch0, farc = swap ? ch0 : ch1;
@@ -484,12 +521,15 @@ __device__ inline int trav_result(const TravState& ts, float& t_out) {
 
 // Whole traversal for one lane (megakernel / test kernels).
 template <bool STATS>
-__device__ inline int bvh_traverse(const DScene& sc, const hrt_mesh& mesh, vec3 o, vec3 d, float t_min, float t_max,
+__device__ inline int bvh_traverse(const DScene& sc, int mi /* mesh index */, vec3 o, vec3 d, float t_min, float t_max,
                                    uint32_t quirks, int* stack /* + threadIdx.x */, float& t_out, DCounters& cnt) {
-    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    const auto& mesh = uniform_table(sc.meshes)[mi];
+    const uint4* nodes = sc.qnodes + 2ull * mesh.node_first;
     const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
     const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
-    const MeshRay r = mesh_ray_setup(o, d, quirks);
+    float4 grid_o, grid_s;
+    mesh_grid(sc, mi, grid_o, grid_s);
+    const MeshRay r = mesh_ray_setup(o, d, quirks, grid_o, grid_s);
     const float t_lo = trav_t_lo(t_min, quirks);
     TravState ts;
     trav_init(ts, mesh, t_max);
@@ -536,13 +576,13 @@ __device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_m
     WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = t_max;
     float closest = t_max;
     for (int i = 0; i < sc.n_prims; ++i) {
-        const hrt_prim& pr = sc.prims[i];
+        const auto& pr = uniform_table(sc.prims)[i];
         vec3 lo = o, ld = d;
         for (int k = 0; k < pr.n_xforms; ++k) xf_apply(pr.xf[k], lo, ld, quirks);
         float t; int sub = -1; bool hit;
         const int kind = pr.kind;
         if (kind == HRT_PRIM_MESH) {
-            sub = bvh_traverse<STATS>(sc, sc.meshes[pr.mesh], lo, ld, t_min, closest, quirks, stack, t, cnt);
+            sub = bvh_traverse<STATS>(sc, pr.mesh, lo, ld, t_min, closest, quirks, stack, t, cnt);
             hit = sub >= 0;
         } else if (kind == HRT_PRIM_SPHERE) {
             hit = sphere_hit(pr.p, lo, ld, t_min, closest, t);
@@ -564,7 +604,7 @@ __device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_m
 __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o, vec3 d, float t_min, uint32_t quirks,
                                        const rng_ctx& ctx, float& closest, int& prim, int& sub) {
     for (int i = p0; i < p1; ++i) {
-        const hrt_prim& pr = sc.prims[i];
+        const auto& pr = uniform_table(sc.prims)[i];
         const int kind = pr.kind;
         if (kind == HRT_PRIM_MESH) continue;
         vec3 lo = o, ld = d;

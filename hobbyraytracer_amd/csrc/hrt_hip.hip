@@ -264,19 +264,39 @@ __device__ inline rng_ctx slot_ctx(const hrt_params& pr, const RenderMap& map, u
     return ctx;
 }
 
+#ifdef HRT_EXT_PROFILE   // debug variant only (build_variants/): where do the traversal waves spend their cycles?
+__device__ unsigned long long g_ext_prof[16];
+__device__ unsigned long long g_shade_prof[16];
+#define PROF_T(v) const long long v = clock64()
+#define PROF_ADD(i, x) prof[i] += (unsigned long long)(x)
+#else
+#define PROF_T(v)
+#define PROF_ADD(i, x)
+#endif
+
 // Preparation of one segment: analytic prims [p0, p1) in list order (closest-so-far semantics of
 // hittableList.cpp:12-19), then the ray in the space of mesh prim `mesh_prim` and the root-box filter.
 template <bool STATS>
 __device__ inline bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
-                                  const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled) {
+                                  const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled,
+                                  unsigned long long* prof = nullptr) {
+    PROF_T(q0);
     prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
     if (mesh_prim < 0) return false;
-    const hrt_prim& mp = sc.prims[mesh_prim];
-    const hrt_mesh& mesh = sc.meshes[mp.mesh];
+    PROF_T(q1);
+    const auto& mp = uniform_table(sc.prims)[mesh_prim];
+    const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
     vec3 lo = o, ld = d;
     for (int k = 0; k < mp.n_xforms; ++k) xf_apply(mp.xf[k], lo, ld, pr.quirks);
-    mr = mesh_ray_setup(lo, ld, pr.quirks);
+    PROF_T(q2);
+    float4 grid_o, grid_s;
+    mesh_grid(sc, mp.mesh, grid_o, grid_s);
+    mr = mesh_ray_setup(lo, ld, pr.quirks, grid_o, grid_s);
+    PROF_T(q3);
     const bool enq = root_may_hit(sc, mesh, mr, trav_t_lo(pr.t_min, pr.quirks), closest);
+#ifdef HRT_EXT_PROFILE
+    { const long long q4 = clock64(); if (prof) { prof[10] += q1 - q0; prof[11] += q2 - q1; prof[12] += q3 - q2; prof[13] += q4 - q3; } }
+#endif
     if (STATS && !enq && mesh.node_count) n_culled++;
     return enq;
 }
@@ -388,9 +408,11 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const hrt_mesh mesh = sc.meshes[sc.prims[mesh_prim].mesh];
-    const float4* nodes = sc.nodes + 4ull * mesh.node_first;
+    const uint4* nodes = sc.qnodes + 2ull * mesh.node_first;
     const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
     const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
+    float4 grid_o, grid_s;
+    mesh_grid(sc, sc.prims[mesh_prim].mesh, grid_o, grid_s);
     const float t_lo = trav_t_lo(pr.t_min, pr.quirks);
     bool has = false;
     unsigned cur_pos = 0, cur_end = 0;   // wave-uniform: unread rays of the wave's current task
@@ -402,7 +424,12 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     ts.cur = HRT_TRAV_DONE;
     unsigned pos = 0;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+#ifdef HRT_EXT_PROFILE
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = clock64();
+#endif
     for (;;) {
+        PROF_T(t0);
         const unsigned long long need = __ballot(!has);
         if (need && !wave_done) {
             while (cur_pos >= cur_end && !wave_done) {
@@ -420,7 +447,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
                     r.o = vec3(e0.x, e0.y, e0.z); r.d = vec3(e1.x, e1.y, e1.z);
                     r.tr.o = r.o; r.tr.sX = e2.x; r.tr.sY = e2.y; r.tr.sZ = e2.z; r.tr.kZ = __float_as_int(e2.w);
                     r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
-                    r.ox = r.o.x * r.idx; r.oy = r.o.y * r.idy; r.oz = r.o.z * r.idz;
+                    mesh_ray_grid(r, grid_o, grid_s);
                     pos = __float_as_uint(e1.w);
                     trav_init(ts, mesh, e0.w);
                     has = true;
@@ -432,6 +459,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             if (wave_done) break;
             continue;
         }
+        PROF_T(t1); PROF_ADD(0, t1 - t0);
         // while-while with postponed leaves: walk inner nodes until at least leaf_num/64 of the wave's
         // busy lanes stand at a leaf (waiting for ALL of them would run the loop at the pace of the slowest
         // lane), then test the leaves together.  Lanes still at an inner node sit the leaf phase out; idle
@@ -441,8 +469,11 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             if (!m_in) break;
             const int n_leaf = __popcll(__ballot(has && trav_at_leaf(ts)));
             if (n_leaf * 64 >= leaf_num * (n_leaf + __popcll(m_in))) break;
+            PROF_ADD(3, 1); PROF_ADD(4, __popcll(m_in));
             if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
         }
+        PROF_T(t2); PROF_ADD(1, t2 - t1);
+        PROF_ADD(5, 1); PROF_ADD(6, __popcll(__ballot(has && trav_at_leaf(ts)))); PROF_ADD(7, __popcll(__ballot(has)));
         if (has) {
             if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
             if (ts.cur == HRT_TRAV_DONE) {
@@ -456,7 +487,12 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
                 has = false;
             }
         }
+        PROF_T(t3); PROF_ADD(2, t3 - t2);
     }
+#ifdef HRT_EXT_PROFILE
+    prof[8] = (unsigned long long)(clock64() - t_begin); prof[9] = 1;
+    if (lane == 0) for (int i = 0; i < 10; ++i) atomicAdd(&g_ext_prof[i], prof[i]);
+#endif
     if (STATS) {
         const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
         if (lane == 0) {
@@ -483,6 +519,10 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     stage_tables(sc, s_tables);
     unsigned n_seg = 0, n_culled = 0;
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
+#ifdef HRT_EXT_PROFILE
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = clock64();
+#endif
     for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
         const unsigned base = task * w.T;
         const unsigned n = w.live[task];
@@ -491,7 +531,12 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
             const unsigned pos = base + j0 + lane;
             float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
             int sub0 = -1;
+            PROF_T(t0);
             if (j0 + lane < n) { a = w.S0[par][pos]; b = w.S1[par][pos]; c = w.S2[par][pos]; sub0 = w.S3[par][pos]; }
+#ifdef HRT_EXT_PROFILE
+            if (__float_as_uint(a.x) == 0x7fc12345u && sub0 == 0x7eadbeef) prof[15]++;   // force the loads to complete here
+#endif
+            PROF_T(t1); PROF_ADD(0, t1 - t0); PROF_ADD(5, 1); PROF_ADD(6, __popcll(__ballot(j0 + lane < n)));
             bool alive = false;
             PathState ps;
             unsigned slot = 0;
@@ -506,11 +551,15 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
                 ctx = slot_ctx(pr, map, slot, n_local, s0, round);
                 prims_range_hit(sc, ws.rest, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
                 WorldHit wh; wh.prim = prim; wh.sub = sub; wh.t = closest;
+                PROF_T(t2); PROF_ADD(1, t2 - t1);
                 const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
                 if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
                 else alive = true;
+                PROF_T(t3); PROF_ADD(2, t3 - t2);
             }
+            PROF_T(t4);
             const unsigned long long ma = __ballot(alive);
+            PROF_ADD(7, __popcll(ma));
             bool enq = false;
             MeshRay mr;
             float closest = __builtin_huge_valf();
@@ -519,16 +568,25 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
                 npos = out + (unsigned)__popcll(ma & lt);
                 int prim = -1, sub = -1;
                 ctx.bounce = (uint32_t)(round + 1);   // the next segment's draws (ConstantMedium::hit inside wf_prepare)
+#ifdef HRT_EXT_PROFILE
+                enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled, prof);
+#else
                 enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
+#endif
                 wf_store_state(w, nxt, npos, ps, closest, slot, prim, sub);
             }
             out += (unsigned)__popcll(ma);
             const unsigned long long me = __ballot(enq);
             if (enq) wf_store_record(w, qpos + (unsigned)__popcll(me & lt), mr, closest, npos);
             qpos += (unsigned)__popcll(me);
+            PROF_T(t5); PROF_ADD(3, t5 - t4);
         }
         if (lane == 0) { w.live[task] = out - base; w.qn[task] = qpos - base; }
     }
+#ifdef HRT_EXT_PROFILE
+    prof[8] = (unsigned long long)(clock64() - t_begin); prof[9] = 1;
+    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_shade_prof[i], prof[i]);
+#endif
     const unsigned seg = wave_sum(n_seg);
     if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
     if (STATS) {
@@ -785,7 +843,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     const size_t head_words = (size_t)D * (n_mesh > 0 ? n_mesh : 1);
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
     int ext_per_cu = 4;                                  // k_wf_ext blocks per CU (32 KB of LDS stacks each)
-    if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu = std::min(5, std::max(1, atoi(e)));
+    if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu = std::min(10, std::max(1, atoi(e)));
     const int ext_blocks = sc->n_cus * ext_per_cu;
     int leaf_num = 48;                                   // k_wf_ext: start the leaf phase when >= 48/64 of the busy lanes wait at a leaf
     if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
@@ -938,10 +996,13 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     UP(d_mats, f->materials, sizeof(hrt_material) * f->n_materials);
     UP(d_texs, f->textures, sizeof(hrt_texture) * f->n_textures);
     UP(d_meshes, f->meshes, sizeof(hrt_mesh) * f->n_meshes);
-    float4* d_nodes;
-    UP(d_nodes, f->nodes, sizeof(hrt_bvh_node) * f->n_nodes);
-
-    // repack triangles into 16-byte aligned records (hrt_pack.h)
+    // repack the BVH into 32-byte culling records and the triangles into 16-byte aligned records (hrt_pack.h)
+    std::vector<uint32_t> qn;
+    std::vector<float> grids;
+    pack_nodes(f, qn, grids);
+    uint4* d_nodes; float4* d_grids;
+    UP(d_nodes, qn.data(), qn.size() * sizeof(uint32_t));
+    UP(d_grids, grids.data(), grids.size() * sizeof(float));
     std::vector<float> pos, attr, box;
     pack_triangles(f, pos, attr, box);
     float4 *d_pos, *d_attr, *d_box;
@@ -958,7 +1019,7 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
 #undef UP
 
     sc->ds.prims = d_prims; sc->ds.mats = d_mats; sc->ds.texs = d_texs; sc->ds.meshes = d_meshes;
-    sc->ds.nodes = d_nodes; sc->ds.tri_pos = d_pos; sc->ds.tri_attr = d_attr; sc->ds.tri_box = d_box;
+    sc->ds.qnodes = d_nodes; sc->ds.grids = d_grids; sc->ds.tri_pos = d_pos; sc->ds.tri_attr = d_attr; sc->ds.tri_box = d_box;
     sc->ds.texels_u8 = d_u8; sc->ds.texels_f32 = d_f32;
     sc->ds.n_prims = (int32_t)f->n_prims;
     sc->ds.background_tex = f->background_tex;
@@ -1014,6 +1075,24 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
     stats->rays = c.rays; stats->samples = c.samples; stats->box_tests = c.box_tests; stats->tri_tests = c.tri_tests;
     stats->mesh_hits = c.mesh_hits; stats->env_lookups = c.env_lookups;
+#ifdef HRT_EXT_PROFILE
+    {
+        unsigned long long h[16], z[16] = {0};
+        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ext_prof), sizeof(h)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ext_prof), z, sizeof(z)));
+        fprintf(stderr, "[ext-prof] waves %llu  cycles/wave %.0f : refill %.1f%% inner %.1f%% leaf %.1f%% | inner iters/wave %.0f lanes/iter %.1f | leaf phases/wave %.0f leaf-lanes %.1f busy-lanes %.1f\n",
+                h[9], (double)h[8] / (h[9] ? h[9] : 1), 100.0 * h[0] / (h[8] ? h[8] : 1), 100.0 * h[1] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[8] ? h[8] : 1),
+                (double)h[3] / (h[9] ? h[9] : 1), (double)h[4] / (h[3] ? h[3] : 1), (double)h[5] / (h[9] ? h[9] : 1), (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / (h[5] ? h[5] : 1));
+        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_prof), sizeof(h)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, sizeof(z)));
+        const double tot = (double)(h[8] ? h[8] : 1);
+        fprintf(stderr, "[shade-prof] waves %llu cycles/wave %.0f : load %.1f%% prims %.1f%% shade %.1f%% prepare+store %.1f%% | chunks/wave %.1f lanes %.1f alive %.1f\n",
+                h[9], tot / (h[9] ? h[9] : 1), 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot,
+                (double)h[5] / (h[9] ? h[9] : 1), (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / (h[5] ? h[5] : 1));
+        fprintf(stderr, "[shade-prof] inside prepare: analytic prims %.1f%% xforms %.1f%% ray setup %.1f%% root test %.1f%%\n",
+                100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot, 100.0 * h[13] / tot);
+    }
+#endif
     stats->kernel_ms = sc->kernel_ms; stats->launches = sc->launches;
     stats->traversal_ms = sc->traversal_ms; stats->traversal_launches = sc->traversal_launches;
     sc->kernel_ms = 0.0; sc->launches = 0; sc->traversal_ms = 0.0; sc->traversal_launches = 0;

@@ -1,7 +1,8 @@
 // hrt_pack.h — host-side repacking of the flat scene's triangle arrays into the
 // 16-byte aligned records the kernels fetch with dwordx4 loads (DScene in
-// hrt_device.h).  Used by hrt_scene_create (hrt_hip.hip).
+// hrt_device.h), and of its BVH nodes into the compact culling records.  Used by hrt_scene_create (hrt_hip.hip).
 #pragma once
+#include <cmath>
 #include <vector>
 
 #include "../../include/hrt.h"
@@ -36,6 +37,67 @@ inline void pack_triangles(const hrt_flat_scene* f, std::vector<float>& pos, std
         }
         const uint32_t ord = f->tri_ref_order ? f->tri_ref_order[i] : ((uint32_t)i << 1);
         b[3] = u2f(ord);
+    }
+}
+
+// Culling nodes: the 64-byte fp32 hrt_bvh_node of the ABI becomes a 32-byte record (two dwordx4 fetches per
+// step instead of four -- the traversal kernel is bound by the L1 tag pipeline, one divergent lane-access per
+// clock) with the child boxes on a 16-bit grid over the mesh's root box:
+//   qnode: 8 words  | c0 x lo|hi<<16 | c0 y | c0 z | child0 | c1 x | c1 y | c1 z | child1 |
+//   grid : 2 x float4 per mesh  origin.xyz _ | step.xyz _          box = origin + q * step
+// Boxes are only ever used to CULL (acceptance uses the reference's exact leaf boxes, tri_box), so any superset
+// is valid: lo is rounded down and hi up until the decoded value, computed with the kernel's own fmaf, encloses
+// the fp32 box.  Empty children (min > max) keep their harmless never-smaller encoding lo=65535, hi=0.
+inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, std::vector<float>& grids) {
+    qnodes.assign((size_t)f->n_nodes * 8, 0u);
+    grids.assign((size_t)f->n_meshes * 8, 0.0f);
+    for (uint32_t m = 0; m < f->n_meshes; ++m) {
+        const hrt_mesh& me = f->meshes[m];
+        float* g = &grids[8 * (size_t)m];
+        for (int a = 0; a < 3; ++a) { g[a] = 0.0f; g[4 + a] = 1.0f; }
+        if (me.node_count == 0) continue;
+        const hrt_bvh_node* nodes = f->nodes + me.node_first;
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t i = 0; i < me.node_count; ++i) {   // (children lie inside their parents up to the rounding guard: take all)
+            const hrt_bvh_node& n = nodes[i];
+            const float b[2][6] = {{n.c0_min_x, n.c0_min_y, n.c0_min_z, n.c0_max_x, n.c0_max_y, n.c0_max_z},
+                                   {n.c1_min_x, n.c1_min_y, n.c1_min_z, n.c1_max_x, n.c1_max_y, n.c1_max_z}};
+            for (int c = 0; c < 2; ++c) {
+                if (b[c][0] > b[c][3]) continue;
+                for (int a = 0; a < 3; ++a) { lo[a] = gmin(lo[a], b[c][a]); hi[a] = gmax(hi[a], b[c][3 + a]); }
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (lo[a] > hi[a]) { lo[a] = 0.0f; hi[a] = 0.0f; }
+            const float ext = hi[a] - lo[a];
+            float step = ext / 65000.0f;                 // head-room: hi must decode to <= 65535 whatever the rounding
+            if (!(step > 1e-30f)) step = 1e-30f;
+            g[a] = lo[a]; g[4 + a] = step;
+        }
+        auto q_lo = [&](float v, int a) {
+            long q = (long)std::floor(((double)v - (double)g[a]) / (double)g[4 + a]);
+            q = q < 0 ? 0 : (q > 65535 ? 65535 : q);
+            while (q > 0 && fmaf((float)q, g[4 + a], g[a]) > v) --q;
+            return (uint32_t)q;
+        };
+        auto q_hi = [&](float v, int a) {
+            long q = (long)std::ceil(((double)v - (double)g[a]) / (double)g[4 + a]);
+            q = q < 0 ? 0 : (q > 65535 ? 65535 : q);
+            while (q < 65535 && fmaf((float)q, g[4 + a], g[a]) < v) ++q;
+            return (uint32_t)q;
+        };
+        for (uint32_t i = 0; i < me.node_count; ++i) {
+            const hrt_bvh_node& n = nodes[i];
+            uint32_t* w = &qnodes[8 * ((size_t)me.node_first + i)];
+            const float b[2][6] = {{n.c0_min_x, n.c0_min_y, n.c0_min_z, n.c0_max_x, n.c0_max_y, n.c0_max_z},
+                                   {n.c1_min_x, n.c1_min_y, n.c1_min_z, n.c1_max_x, n.c1_max_y, n.c1_max_z}};
+            const int32_t ch[2] = {n.child0, n.child1};
+            for (int c = 0; c < 2; ++c) {
+                for (int a = 0; a < 3; ++a)
+                    w[4 * c + a] = b[c][0] > b[c][3] ? 65535u : (q_lo(b[c][a], a) | (q_hi(b[c][3 + a], a) << 16));
+                w[4 * c + 3] = (uint32_t)ch[c];
+            }
+        }
     }
 }
 

@@ -12,6 +12,7 @@
 
 #define __device__
 struct float4 { float x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 
 #include "../../hobbyraytracer_amd/csrc/hrt_device.h"
@@ -21,14 +22,16 @@ using namespace hrt;
 
 namespace {
 struct CpuScene {
-    std::vector<float> pos, attr, box;
+    std::vector<float> pos, attr, box, grids;
+    std::vector<uint32_t> qnodes;
     DScene ds;
 };
 CpuScene* make(const hrt_flat_scene* f) {
     CpuScene* s = new CpuScene;
     pack_triangles(f, s->pos, s->attr, s->box);
     s->ds.prims = f->prims; s->ds.mats = f->materials; s->ds.texs = f->textures; s->ds.meshes = f->meshes;
-    s->ds.nodes = (const float4*)f->nodes;
+    pack_nodes(f, s->qnodes, s->grids);
+    s->ds.qnodes = (const uint4*)s->qnodes.data(); s->ds.grids = (const float4*)s->grids.data();
     s->ds.tri_pos = (const float4*)s->pos.data(); s->ds.tri_attr = (const float4*)s->attr.data(); s->ds.tri_box = (const float4*)s->box.data();
     s->ds.texels_u8 = f->texels_u8; s->ds.texels_f32 = f->texels_f32;
     s->ds.n_prims = (int32_t)f->n_prims; s->ds.background_tex = f->background_tex;
