@@ -400,10 +400,12 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
 
 // Persistent BVH traversal of the queued rays of one mesh prim.  A wave walks its tasks (strided static
 // ownership) and hands their rays to its lanes as they fall idle (ballot + prefix count, no atomics).
-template <bool STATS>
+// DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
+// leave room for more resident blocks per CU (16 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
+template <bool STATS, int DEPTH>
 __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w, unsigned* head,
                                                       DeviceCounters* counters, int leaf_num) {
-    __shared__ int s_stack[HRT_STACK_DEPTH * HRT_BLOCK];
+    __shared__ int s_stack[DEPTH * HRT_BLOCK];
     int* stack = s_stack + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -661,6 +663,7 @@ struct hrt_scene {
     DScene ds{};
     std::vector<void*> allocs;
     std::vector<int> mesh_prims;   // indices of the HRT_PRIM_MESH entries of the world list, in list order
+    std::vector<int> mesh_depths;  // BVH depth of each of them (selects the traversal kernel's stack size)
     int n_prims = 0;
     DeviceCounters* d_counters = nullptr;
     unsigned* d_work = nullptr;
@@ -760,6 +763,22 @@ hrt_status validate(const hrt_flat_scene* f) {
     return HRT_OK;
 }
 
+// Depth of a (validated) mesh BVH: the deepest inner node, root = 1 (what validate() bounds by HRT_STACK_DEPTH).
+int bvh_depth(const hrt_flat_scene* f, const hrt_mesh& m) {
+    int deepest = 0;
+    if (!m.node_count) return deepest;
+    std::vector<std::pair<int32_t, int>> st;
+    st.push_back({0, 1});
+    while (!st.empty()) {
+        auto [ni, depth] = st.back(); st.pop_back();
+        deepest = std::max(deepest, depth);
+        const hrt_bvh_node& n = f->nodes[m.node_first + ni];
+        if (!(n.c0_min_x > n.c0_max_x) && n.child0 >= 0) st.push_back({n.child0, depth + 1});
+        if (!(n.c1_min_x > n.c1_max_x) && n.child1 >= 0) st.push_back({n.child1, depth + 1});
+    }
+    return deepest;
+}
+
 hrt_status check_params(const hrt_params* p) {
     if (!p) return fail(HRT_ERR_INVALID, "params is NULL");
     if (p->width < 2 || p->height < 2) return fail(HRT_ERR_INVALID, "film must be at least 2x2 (main.cpp:120-121 divides by W-1, H-1)");
@@ -842,9 +861,8 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     ws.rest = n_mesh > 0 ? sc->mesh_prims.back() + 1 : sc->n_prims;
     const size_t head_words = (size_t)D * (n_mesh > 0 ? n_mesh : 1);
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
-    int ext_per_cu = 4;                                  // k_wf_ext blocks per CU (32 KB of LDS stacks each)
-    if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu = std::min(10, std::max(1, atoi(e)));
-    const int ext_blocks = sc->n_cus * ext_per_cu;
+    int ext_per_cu_env = 0;                              // experiments: k_wf_ext blocks per CU
+    if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu_env = std::min(10, std::max(1, atoi(e)));
     int leaf_num = 48;                                   // k_wf_ext: start the leaf phase when >= 48/64 of the busy lanes wait at a leaf
     if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
     leaf_num = std::min(64, std::max(1, leaf_num));      // >= 1: with no lane at a leaf the inner loop must go on
@@ -873,8 +891,14 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 }
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (timing) { st = get_event(sc, &ea); if (st != HRT_OK) return st; st = get_event(sc, &eb); if (st != HRT_OK) return st; HIPCHK(hipEventRecord(ea, stream)); }
-                if (stats) hipLaunchKernelGGL(k_wf_ext<true>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num);
-                else hipLaunchKernelGGL(k_wf_ext<false>, dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num);
+                // stack depth variant: LDS per block = DEPTH KB; resident blocks per CU: LDS 160 KB and 78 VGPRs -> 6 waves/SIMD
+                const int md = sc->mesh_depths[m];
+                const int variant = md <= 16 ? 16 : (md <= 24 ? 24 : 32);
+                const int ext_blocks = sc->n_cus * (ext_per_cu_env ? ext_per_cu_env : (variant == 32 ? 4 : 6));
+#define HRT_LAUNCH_EXT(S, D) hipLaunchKernelGGL((k_wf_ext<S, D>), dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num)
+                if (stats) { if (variant == 16) HRT_LAUNCH_EXT(true, 16); else if (variant == 24) HRT_LAUNCH_EXT(true, 24); else HRT_LAUNCH_EXT(true, 32); }
+                else { if (variant == 16) HRT_LAUNCH_EXT(false, 16); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
+#undef HRT_LAUNCH_EXT
                 if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
             }
             if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
@@ -1027,7 +1051,10 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     sc->ds.n_mats = (int32_t)f->n_materials; sc->ds.n_texs = (int32_t)f->n_textures; sc->ds.n_meshes = (int32_t)f->n_meshes;
     sc->n_prims = (int)f->n_prims;
     for (uint32_t i = 0; i < f->n_prims; ++i)
-        if (f->prims[i].kind == HRT_PRIM_MESH) sc->mesh_prims.push_back((int)i);
+        if (f->prims[i].kind == HRT_PRIM_MESH) {
+            sc->mesh_prims.push_back((int)i);
+            sc->mesh_depths.push_back(bvh_depth(f, f->meshes[f->prims[i].mesh]));
+        }
     *out = sc;
     return HRT_OK;
 }

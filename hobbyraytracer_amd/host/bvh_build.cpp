@@ -16,6 +16,7 @@
 // then decides exactly as the reference would.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -89,7 +90,7 @@ struct SahBuilder {
     struct Ref { Box3 b; float c[3]; uint32_t tri; };
     std::vector<Ref> refs;
     std::vector<hrt_bvh_node> nodes;
-    int maxLeaf = 4;
+    int maxLeaf = 2;     // measured on MI355X (tests/tools/sweep_bvh.py): 2 beats 1, 3, 4, 8 by 3-12 % of traversal time on teapot and bust
     int sahLevels = 31;  // depth budget: SAH only while depth + ceil(log2 n) + 1 < sahLevels
     int maxDepth = 0;
     float triCost = 1.3f, boxCost = 1.0f;
@@ -251,6 +252,9 @@ BVHNode::BVHNode(TriangleSoup& soup) {
         return;
     }
     SahBuilder sb;
+    // tuning knobs (experiments only; the defaults are what the tests and the bench use)
+    if (const char* e = std::getenv("HRT_BVH_MAX_LEAF")) sb.maxLeaf = std::min(8, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("HRT_BVH_TRI_COST")) sb.triCost = (float)std::atof(e);
     sb.refs.resize(n);
     for (size_t i = 0; i < n; ++i) {
         SahBuilder::Ref& r = sb.refs[i];

@@ -14,7 +14,7 @@ fs=glob.glob("$d/*/*_counter_collection.csv")
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
 for r in csv.DictReader(open(fs[0])):
     n=r["Kernel_Name"]
-    if "<true>" in n or not ("k_wf" in n or "k_pathtrace" in n): continue
+    if "<true" in n or not ("k_wf" in n or "k_pathtrace" in n): continue
     k=n.split("(anonymous namespace)::")[-1].split("<")[0].split("(")[0]
     acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
     calls[(k,r["Counter_Name"])]+=1
