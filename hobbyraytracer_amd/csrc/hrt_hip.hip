@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
 // Persistent BVH traversal of the queued rays of one mesh prim.  A wave walks its tasks (strided static
 // ownership) and hands their rays to its lanes as they fall idle (ballot + prefix count, no atomics).
 // DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
-// leave room for more resident blocks per CU (16 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
+// leave room for more resident blocks per CU (20 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
 template <bool STATS, int DEPTH>
 __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w, unsigned* head,
                                                       DeviceCounters* counters, int leaf_num) {
@@ -893,11 +893,11 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 if (timing) { st = get_event(sc, &ea); if (st != HRT_OK) return st; st = get_event(sc, &eb); if (st != HRT_OK) return st; HIPCHK(hipEventRecord(ea, stream)); }
                 // stack depth variant: LDS per block = DEPTH KB; resident blocks per CU: LDS 160 KB and 78 VGPRs -> 6 waves/SIMD
                 const int md = sc->mesh_depths[m];
-                const int variant = md <= 16 ? 16 : (md <= 24 ? 24 : 32);
+                const int variant = md <= 20 ? 20 : (md <= 24 ? 24 : 32);
                 const int ext_blocks = sc->n_cus * (ext_per_cu_env ? ext_per_cu_env : (variant == 32 ? 4 : 6));
 #define HRT_LAUNCH_EXT(S, D) hipLaunchKernelGGL((k_wf_ext<S, D>), dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num)
-                if (stats) { if (variant == 16) HRT_LAUNCH_EXT(true, 16); else if (variant == 24) HRT_LAUNCH_EXT(true, 24); else HRT_LAUNCH_EXT(true, 32); }
-                else { if (variant == 16) HRT_LAUNCH_EXT(false, 16); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
+                if (stats) { if (variant == 20) HRT_LAUNCH_EXT(true, 20); else if (variant == 24) HRT_LAUNCH_EXT(true, 24); else HRT_LAUNCH_EXT(true, 32); }
+                else { if (variant == 20) HRT_LAUNCH_EXT(false, 20); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
 #undef HRT_LAUNCH_EXT
                 if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
             }
