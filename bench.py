@@ -175,9 +175,12 @@ def main():
         #   launches = its launches per frame (one per round per mesh), time = HIP events around each launch.
         #   megakernel: k_pathtrace, all of SURVEY §8(d)'s bytes, one launch per frame.
         frame_ms = float(kern.item())
+        roof_note = None
         if args.megakernel or st.traversal_launches == 0:
-            kname, k_launches = "k_pathtrace", 1
+            kname, k_launches = ("k_pathtrace" if args.megakernel else "k_wf_gen+k_wf_shade+k_wf_reduce (whole frame)"), 1
             k_bytes, k_ms = float(alg_bytes_launch), frame_ms
+            if not args.megakernel:   # a scene without a mesh has no BVH traversal: fp32 VALU / divergence bound
+                roof_note = "no mesh in this scene: the frame moves almost no memory, an HBM fraction is not meaningful (VALU / divergence bound)"
         else:
             kname, k_launches = "k_wf_ext", st.traversal_launches / max(1, st.launches)
             k_bytes = (32.0 * st_count.box_tests + 36.0 * st_count.tri_tests) / k_launches
@@ -226,6 +229,8 @@ def main():
                          "box_tests_per_ray": round(st_count.box_tests / max(1, st_count.rays), 3),
                          "tri_tests_per_ray": round(st_count.tri_tests / max(1, st_count.rays), 3)},
         }
+        if roof_note:
+            result["roofline"]["note"] = roof_note
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
             from oracle import oracle_py as orc
             cores = host_cores()

@@ -472,6 +472,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             const int n_leaf = __popcll(__ballot(has && trav_at_leaf(ts)));
             if (n_leaf * 64 >= leaf_num * (n_leaf + __popcll(m_in))) break;
             PROF_ADD(3, 1); PROF_ADD(4, __popcll(m_in));
+            // two node steps per vote: the wave-level bookkeeping (two ballots, counts, compare, branch) is a
+            // third of a step's instructions
+            if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
             if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
         }
         PROF_T(t2); PROF_ADD(1, t2 - t1);
