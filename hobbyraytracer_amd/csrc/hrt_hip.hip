@@ -507,11 +507,38 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     }
 }
 
+// Paths that escaped (main.cpp:47-58) wait in a per-wave LDS queue until 64 of them can evaluate the background
+// together: the environment lookup (normalize, atan2, acos, texel fetch: ~300 instructions) otherwise runs at
+// the 10 % lane occupancy of "the lanes of this chunk that happened to miss".
+#define HRT_MISSQ_CAP 128
+struct MissQueue {            // one per wave; SoA rows of HRT_MISSQ_CAP entries: d.xyz, atten.xyz, slot
+    float* f;                 // 6 rows
+    unsigned* slot;           // 1 row
+    unsigned count;           // wave-uniform
+};
+template <bool STATS>
+__device__ inline void missq_flush(const DScene& sc, const WfBuf& w, MissQueue& q, unsigned lane, unsigned n, PathCounters& pc) {
+    // the last n (<= 64) entries
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < n) {
+        const unsigned e = q.count - n + lane;
+        const vec3 d(q.f[0 * HRT_MISSQ_CAP + e], q.f[1 * HRT_MISSQ_CAP + e], q.f[2 * HRT_MISSQ_CAP + e]);
+        const vec3 atten(q.f[3 * HRT_MISSQ_CAP + e], q.f[4 * HRT_MISSQ_CAP + e], q.f[5 * HRT_MISSQ_CAP + e]);
+        const unsigned slot = q.slot[e];
+        if (STATS && sc.ltexs[sc.background_tex].kind == HRT_TEX_ENV) pc.env_lookups++;
+        vec3 result(0.0f);
+        result += atten * background_value(sc, d);       // path_shade's miss branch, same operations
+        w.rad[slot] = make_float4(result.x, result.y, result.z, 0.0f);
+    }
+    q.count -= n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // The rest of the segment (analytic prims behind the last mesh, main.cpp:46-76) for every live path, and,
 // for the survivors, the preparation of their next segment.  Survivors are written compacted, in order,
 // to the other state copy.
 #ifndef HRT_SHADE_WAVES
-#define HRT_SHADE_WAVES 1
+#define HRT_SHADE_WAVES 4   // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
 template <bool STATS>
 __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hrt_params pr, RenderMap map, WfScene ws, unsigned n_local, int s0, int round,
@@ -521,7 +548,10 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int par = round & 1, nxt = par ^ 1;
     __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
+    __shared__ float s_missq[4][7 * HRT_MISSQ_CAP];
     stage_tables(sc, s_tables);
+    MissQueue mq;
+    mq.f = s_missq[threadIdx.x >> 6]; mq.slot = (unsigned*)(mq.f + 6 * HRT_MISSQ_CAP); mq.count = 0;
     unsigned n_seg = 0, n_culled = 0;
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
 #ifdef HRT_EXT_PROFILE
@@ -546,6 +576,8 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
             PathState ps;
             unsigned slot = 0;
             rng_ctx ctx; ctx.seed_lo = 0; ctx.seed_hi = 0; ctx.pixel = 0; ctx.sample = 0; ctx.bounce = 0;
+            bool missed = false;
+            WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = 0.0f;
             if (j0 + lane < n) {
                 n_seg++;
                 ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(b.x, b.y, b.z);
@@ -555,13 +587,29 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
                 int prim = __float_as_int(c.w), sub = sub0;
                 ctx = slot_ctx(pr, map, slot, n_local, s0, round);
                 prims_range_hit(sc, ws.rest, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
-                WorldHit wh; wh.prim = prim; wh.sub = sub; wh.t = closest;
-                PROF_T(t2); PROF_ADD(1, t2 - t1);
+                wh.prim = prim; wh.sub = sub; wh.t = closest;
+                missed = prim < 0;
+            }
+            PROF_T(t2); PROF_ADD(1, t2 - t1);
+            {   // escaped paths: queue them; evaluate the background 64 at a time
+                const unsigned long long mm = __ballot(missed);
+                if (mm) {
+                    if (missed) {
+                        const unsigned e = mq.count + (unsigned)__popcll(mm & lt);
+                        mq.f[0 * HRT_MISSQ_CAP + e] = ps.d.x; mq.f[1 * HRT_MISSQ_CAP + e] = ps.d.y; mq.f[2 * HRT_MISSQ_CAP + e] = ps.d.z;
+                        mq.f[3 * HRT_MISSQ_CAP + e] = ps.atten.x; mq.f[4 * HRT_MISSQ_CAP + e] = ps.atten.y; mq.f[5 * HRT_MISSQ_CAP + e] = ps.atten.z;
+                        mq.slot[e] = slot;
+                    }
+                    mq.count += (unsigned)__popcll(mm);       // <= 63 + 64 < HRT_MISSQ_CAP
+                    if (mq.count >= 64) missq_flush<STATS>(sc, w, mq, lane, 64, pc);
+                }
+            }
+            if (j0 + lane < n && !missed) {
                 const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
                 if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
                 else alive = true;
-                PROF_T(t3); PROF_ADD(2, t3 - t2);
             }
+            PROF_T(t3); PROF_ADD(2, t3 - t2);
             PROF_T(t4);
             const unsigned long long ma = __ballot(alive);
             PROF_ADD(7, __popcll(ma));
@@ -588,6 +636,7 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
         }
         if (lane == 0) { w.live[task] = out - base; w.qn[task] = qpos - base; }
     }
+    if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
 #ifdef HRT_EXT_PROFILE
     prof[8] = (unsigned long long)(clock64() - t_begin); prof[9] = 1;
     if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_shade_prof[i], prof[i]);
