@@ -427,8 +427,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     unsigned pos = 0;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
 #ifdef HRT_EXT_PROFILE
-    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
+    unsigned my_steps = 0;
 #endif
     for (;;) {
         PROF_T(t0);
@@ -453,6 +454,9 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
                     pos = __float_as_uint(e1.w);
                     trav_init(ts, mesh, e0.w);
                     has = true;
+#ifdef HRT_EXT_PROFILE
+                    my_steps = 0;
+#endif
                 }
                 cur_pos += (unsigned)__popcll(need);
             }
@@ -474,7 +478,13 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             PROF_ADD(3, 1); PROF_ADD(4, __popcll(m_in));
             // two node steps per vote: the wave-level bookkeeping (two ballots, counts, compare, branch) is a
             // third of a step's instructions
+#ifdef HRT_EXT_PROFILE
+            if (has && trav_at_inner(ts)) my_steps++;
+#endif
             if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
+#ifdef HRT_EXT_PROFILE
+            if (has && trav_at_inner(ts)) my_steps++;
+#endif
             if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
         }
         PROF_T(t2); PROF_ADD(1, t2 - t1);
@@ -482,6 +492,13 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
         if (has) {
             if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
             if (ts.cur == HRT_TRAV_DONE) {
+#ifdef HRT_EXT_PROFILE
+                {
+                    const unsigned long long dn = __ballot(true);
+                    prof[10] += __popcll(dn); prof[11] += __popcll(__ballot(my_steps <= 2)); prof[12] += __popcll(__ballot(my_steps <= 4));
+                    prof[13] += __popcll(__ballot(my_steps <= 8)); prof[14] += __popcll(__ballot(trav_result(ts, *(float*)&my_steps) >= 0));
+                }
+#endif
                 float t;
                 const int tri = trav_result(ts, t);
                 if (tri >= 0) {
@@ -496,7 +513,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     }
 #ifdef HRT_EXT_PROFILE
     prof[8] = (unsigned long long)(clock64() - t_begin); prof[9] = 1;
-    if (lane == 0) for (int i = 0; i < 10; ++i) atomicAdd(&g_ext_prof[i], prof[i]);
+    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_ext_prof[i], prof[i]);
 #endif
     if (STATS) {
         const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
@@ -1162,6 +1179,8 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
         fprintf(stderr, "[ext-prof] waves %llu  cycles/wave %.0f : refill %.1f%% inner %.1f%% leaf %.1f%% | inner iters/wave %.0f lanes/iter %.1f | leaf phases/wave %.0f leaf-lanes %.1f busy-lanes %.1f\n",
                 h[9], (double)h[8] / (h[9] ? h[9] : 1), 100.0 * h[0] / (h[8] ? h[8] : 1), 100.0 * h[1] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[8] ? h[8] : 1),
                 (double)h[3] / (h[9] ? h[9] : 1), (double)h[4] / (h[3] ? h[3] : 1), (double)h[5] / (h[9] ? h[9] : 1), (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / (h[5] ? h[5] : 1));
+        fprintf(stderr, "[ext-prof] rays %llu : <=2 node steps %.1f%%  <=4 %.1f%%  <=8 %.1f%%  hit a triangle %.1f%%\n", h[10], 100.0 * h[11] / (h[10] ? h[10] : 1),
+                100.0 * h[12] / (h[10] ? h[10] : 1), 100.0 * h[13] / (h[10] ? h[10] : 1), 100.0 * h[14] / (h[10] ? h[10] : 1));
         HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_prof), sizeof(h)));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, sizeof(z)));
         const double tot = (double)(h[8] ? h[8] : 1);

@@ -74,6 +74,60 @@ def test_bvh_structure(built, assets, scenes_dir, scene):
     assert counts.max() <= 2 and len(np.unique(order)) == m.tri_count     # 1- or 2-object lowest nodes (bvh.cpp:20-36)
 
 
+@pytest.mark.parametrize("scene", ["teapot_scene.yaml", "bust_scene.yaml"])
+def test_packed_culling_nodes_enclose_the_fp32_boxes(built, assets, scenes_dir, tools, scene):
+    """The 32-byte grid records the kernels traverse (hrt_pack.h pack_nodes) may only ever be LOOSER than the
+    fp32 child boxes of the ABI's hrt_bvh_node, decoded with the kernel's own fmaf; and not looser than two
+    grid cells, or culling would degrade silently."""
+    _, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
+    flat = hs.flat
+    qn, grids = FlatCpu(hs.flat_ptr).packed_nodes()
+    assert qn.shape[0] == flat.n_nodes and grids.shape[0] == flat.n_meshes
+    m, nodes = _walk_bvh(flat, 0)
+    origin, step = grids[0, 0:3].astype(np.float64), grids[0, 4:7].astype(np.float64)
+    assert (step > 0).all()
+    f32 = np.array([[n.c0_min_x, n.c0_min_y, n.c0_min_z, n.c0_max_x, n.c0_max_y, n.c0_max_z,
+                     n.c1_min_x, n.c1_min_y, n.c1_min_z, n.c1_max_x, n.c1_max_y, n.c1_max_z] for n in nodes], dtype=np.float32).reshape(-1, 2, 2, 3)
+    q = qn[m.node_first:m.node_first + m.node_count]
+    lo = np.stack([q[:, [0, 1, 2]] & 0xffff, q[:, [4, 5, 6]] & 0xffff], 1).astype(np.float32)     # [node, child, axis]
+    hi = np.stack([q[:, [0, 1, 2]] >> 16, q[:, [4, 5, 6]] >> 16], 1).astype(np.float32)
+    # decode exactly like the host check: fl(q * step + origin) with one rounding (float64 product of two float32 is exact)
+    dec_lo = (lo.astype(np.float64) * step + origin).astype(np.float32)
+    dec_hi = (hi.astype(np.float64) * step + origin).astype(np.float32)
+    empty = f32[:, :, 0, 0] > f32[:, :, 1, 0]
+    ok = ~empty
+    assert (dec_lo[ok] <= f32[:, :, 0][ok]).all() and (dec_hi[ok] >= f32[:, :, 1][ok]).all()
+    assert ((f32[:, :, 0][ok] - dec_lo[ok]) <= 2 * step + 1e-6).all() and ((dec_hi[ok] - f32[:, :, 1][ok]) <= 2 * step + 1e-6).all()
+    children = np.stack([q[:, 3], q[:, 7]], 1).view(np.int32)
+    assert np.array_equal(children, np.array([[n.child0, n.child1] for n in nodes], dtype=np.int32))
+
+
+def test_image_does_not_depend_on_the_culling_tree(built, assets, scenes_dir, tools, monkeypatch):
+    """The BVH only culls: with quirks=fixed (no Q-2 self-hits, whose winner follows the RESTATED reference tree,
+    which is built over the leaf-ordered soup and so moves with the builder's settings) any builder setting must give
+    the same film bit for bit, and the same film as the oracle."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    W, H, spp = 40, 40, 4
+    p = api.default_params(W, H, spp, quirks=api.QUIRKS_FIXED)
+    films = []
+    for max_leaf, tri_cost in ((None, None), ("1", "1.3"), ("4", "0.7"), ("8", "3.0")):
+        if max_leaf is None:
+            monkeypatch.delenv("HRT_BVH_MAX_LEAF", raising=False); monkeypatch.delenv("HRT_BVH_TRI_COST", raising=False)
+        else:
+            monkeypatch.setenv("HRT_BVH_MAX_LEAF", max_leaf); monkeypatch.setenv("HRT_BVH_TRI_COST", tri_cost)
+        hs = api.HostScene(f"{scenes_dir}/shiny_teapot.yaml", assets)
+        cam = hs.camera(W, H)
+        a, _ = FlatCpu(hs.flat_ptr).render_tile(cam, p)
+        b, _ = orc.World(hs.flat_ptr).render_tile(cam, p)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        films.append(a)
+    for f in films[1:]:
+        assert np.array_equal(f.view(np.uint32), films[0].view(np.uint32))
+
+
 def test_degenerate_meshes(built, tmp_path, tools):
     """Single triangle (root leaf) and the two-triangle case: flattened result == oracle."""
     orc, FlatCpu = tools

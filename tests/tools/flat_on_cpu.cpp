@@ -46,6 +46,10 @@ extern "C" {
 void* flatcpu_create(const hrt_flat_scene* f) { return make(f); }
 void flatcpu_destroy(void* h) { delete (CpuScene*)h; }
 
+// the packed culling records the product uploads (hrt_pack.h pack_nodes): 8 words per node, 8 floats per mesh
+const uint32_t* flatcpu_qnodes(void* h, uint64_t* n_words) { CpuScene* s = (CpuScene*)h; *n_words = s->qnodes.size(); return s->qnodes.data(); }
+const float* flatcpu_grids(void* h, uint64_t* n_floats) { CpuScene* s = (CpuScene*)h; *n_floats = s->grids.size(); return s->grids.data(); }
+
 void flatcpu_closest_hit(void* h, const hrt_params* pr, int64_t n, const float* ro, const float* rd, float t_min, float t_max,
                          uint32_t pixel0, hrt_hit* out) {
     const DScene& sc = ((CpuScene*)h)->ds;

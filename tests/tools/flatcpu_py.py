@@ -20,6 +20,10 @@ _lib.flatcpu_closest_hit.argtypes = [C.c_void_p, C.POINTER(api.Params), C.c_int6
 _lib.flatcpu_closest_hit.restype = None
 _lib.flatcpu_render_tile.argtypes = [C.c_void_p, C.POINTER(api.Camera), C.POINTER(api.Params), api.Rect, _fp, C.POINTER(api.Stats)]
 _lib.flatcpu_render_tile.restype = None
+_lib.flatcpu_qnodes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+_lib.flatcpu_qnodes.restype = C.POINTER(C.c_uint32)
+_lib.flatcpu_grids.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+_lib.flatcpu_grids.restype = _fp
 
 
 class FlatCpu:
@@ -34,6 +38,15 @@ class FlatCpu:
 
     def __del__(self):
         self.close()
+
+    def packed_nodes(self):
+        """(qnodes [n_nodes, 8] uint32, grids [n_meshes, 8] float32) exactly as the product uploads them."""
+        n = C.c_uint64()
+        q = _lib.flatcpu_qnodes(self._h, C.byref(n))
+        qn = np.ctypeslib.as_array(q, shape=(n.value,)).reshape(-1, 8).copy() if n.value else np.zeros((0, 8), np.uint32)
+        g = _lib.flatcpu_grids(self._h, C.byref(n))
+        gr = np.ctypeslib.as_array(g, shape=(n.value,)).reshape(-1, 8).copy() if n.value else np.zeros((0, 8), np.float32)
+        return qn, gr
 
     def closest_hit(self, params, origins, dirs, t_min=0.001, t_max=float("inf"), pixel0=0):
         o = np.ascontiguousarray(origins, dtype=np.float32)
