@@ -121,7 +121,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<i4"), ("tri", "<i4"), ("front_fac
 assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 HIP_SYMBOLS = ["hrt_device_count", "hrt_scene_create", "hrt_scene_destroy", "hrt_render_tile", "hrt_render_stripes_device",
-               "hrt_render_stripes", "hrt_stripe_rows", "hrt_stripe_row_index", "hrt_scene_stats", "hrt_resolve_u8",
+               "hrt_render_stripes", "hrt_render_stripes_accumulate_device", "hrt_render_stripes_accumulate", "hrt_stripe_rows", "hrt_stripe_row_index", "hrt_scene_stats", "hrt_resolve_u8",
                "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version"]
 HOST_SYMBOLS = ["hrt_host_load_yaml", "hrt_host_free", "hrt_host_flat", "hrt_host_film", "hrt_host_camera", "hrt_host_bvh_depth",
                 "hrt_default_params", "hrt_asset_write_teapot_obj", "hrt_asset_write_bust_obj", "hrt_asset_write_hall_hdr",
@@ -152,6 +152,10 @@ _hip.hrt_scene_destroy.restype = None
 _hip.hrt_render_tile.argtypes = [_vp, C.POINTER(Camera), C.POINTER(Params), Rect, _fp, C.POINTER(Stats)]
 _hip.hrt_render_stripes_device.argtypes = [_vp, C.POINTER(Camera), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, _vp, _vp]
 _hip.hrt_render_stripes.argtypes = [_vp, C.POINTER(Camera), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(Stats)]
+_hip.hrt_render_stripes_accumulate_device.argtypes = [_vp, C.POINTER(Camera), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, _vp,
+                                                      C.c_int32, C.c_int32, _vp]
+_hip.hrt_render_stripes_accumulate.argtypes = [_vp, C.POINTER(Camera), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, _fp,
+                                               C.c_int32, C.c_int32, C.POINTER(Stats)]
 _hip.hrt_stripe_rows.argtypes = [C.c_int32] * 4
 _hip.hrt_stripe_rows.restype = C.c_int32
 _hip.hrt_stripe_row_index.argtypes = [C.c_int32] * 5
@@ -316,6 +320,10 @@ def stripe_rows(height, rows_per_block, rank, n_ranks):
     return _hip.hrt_stripe_rows(height, rows_per_block, rank, n_ranks)
 
 
+def stripe_row_index(height, rows_per_block, rank, n_ranks, local_row):
+    return _hip.hrt_stripe_row_index(height, rows_per_block, rank, n_ranks, local_row)
+
+
 def stripe_row_indices(height, rows_per_block, rank, n_ranks):
     n = stripe_rows(height, rows_per_block, rank, n_ranks)
     return np.array([_hip.hrt_stripe_row_index(height, rows_per_block, rank, n_ranks, i) for i in range(n)], dtype=np.int64)
@@ -362,6 +370,19 @@ class DeviceScene:
         """Asynchronous: d_out_ptr is a device pointer (e.g. torch tensor .data_ptr()), stream a hipStream_t value."""
         _check(_hip.hrt_render_stripes_device(self._h, C.byref(cam), C.byref(params), rows_per_block, rank, n_ranks,
                                               _vp(d_out_ptr), _vp(stream)))
+
+    def render_stripes_accumulate(self, cam, params, rows_per_block, rank, n_ranks, accum, sample_first, sample_count):
+        """Progressive pass: adds samples [sample_first, sample_first + sample_count) to the host array `accum`
+        (rows x W x 3 float32, running sums; divided by params.samples by the pass that reaches it)."""
+        assert accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"]
+        st = Stats()
+        _check(_hip.hrt_render_stripes_accumulate(self._h, C.byref(cam), C.byref(params), rows_per_block, rank, n_ranks, _ptr(accum),
+                                                  sample_first, sample_count, C.byref(st)))
+        return st
+
+    def render_stripes_accumulate_device(self, cam, params, rows_per_block, rank, n_ranks, d_accum_ptr, sample_first, sample_count, stream=0):
+        _check(_hip.hrt_render_stripes_accumulate_device(self._h, C.byref(cam), C.byref(params), rows_per_block, rank, n_ranks,
+                                                         _vp(d_accum_ptr), sample_first, sample_count, _vp(stream)))
 
     def stats(self):
         st = Stats()

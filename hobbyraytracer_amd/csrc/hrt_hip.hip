@@ -912,13 +912,16 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
 }
 
 // render() as the wavefront pipeline: see the comment above struct WfBuf.
+// Samples [s_first, s_first + s_count) of pr->samples are added, in sample order, to the sums held in d_out
+// (s_first == 0 starts them); the batch that reaches pr->samples divides (main.cpp:126).
 hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
-                            hipStream_t stream) {
+                            hipStream_t stream, int s_first, int s_count) {
     const unsigned n_local = (unsigned)map.rw * (unsigned)map.rh;
     const int D = pr->max_depth;
     const int n_mesh = (int)sc->mesh_prims.size();
     size_t cap = wf_max_slots();
-    int chunk = (int)std::min<size_t>((size_t)pr->samples, std::max<size_t>(1, cap / n_local));
+    const int s_end = s_first + s_count;
+    int chunk = (int)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local));
     const size_t slots = (size_t)n_local * chunk;
     if (slots >= ((size_t)1 << 32) - 4096) return fail(HRT_ERR_UNSUPPORTED, "tile too large for 32-bit slot ids");
     hrt_status st = wf_reserve(sc, slots, D);
@@ -936,8 +939,8 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
     leaf_num = std::min(64, std::max(1, leaf_num));      // >= 1: with no lane at a leaf the inner loop must go on
 
-    for (int s0 = 0; s0 < pr->samples; s0 += chunk) {
-        const int c = std::min(chunk, pr->samples - s0);
+    for (int s0 = s_first; s0 < s_end; s0 += chunk) {
+        const int c = std::min(chunk, s_end - s0);
         const unsigned n_slots = n_local * (unsigned)c;
         // task size: ~64 tasks per CU so the tail is short, between 256 and 4096 positions, a multiple of 64
         size_t T = (n_slots / ((size_t)sc->n_cus * 64) + 63) & ~(size_t)63;
@@ -981,8 +984,12 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
 }
 
 hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, const RenderMap& map, float* d_out,
-                            hipStream_t stream) {
+                            hipStream_t stream, int s_first = 0, int s_count = -1) {
     if (map.total_items <= 0) return HRT_OK;
+    if (s_count < 0) s_count = pr->samples - s_first;
+    if (s_first < 0 || s_count < 1 || s_first + s_count > pr->samples) return fail(HRT_ERR_INVALID, "sample range outside [0, samples)");
+    if ((pr->flags & HRT_FLAG_MEGAKERNEL) && (s_first != 0 || s_count != pr->samples))
+        return fail(HRT_ERR_UNSUPPORTED, "the megakernel path renders all samples in one launch (no partial sample ranges)");
     hipEvent_t a, b;
     hrt_status st = get_event(sc, &a);
     if (st != HRT_OK) return st;
@@ -990,7 +997,7 @@ hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     if (st != HRT_OK) return st;
     HIPCHK(hipEventRecord(a, stream));
     st = (pr->flags & HRT_FLAG_MEGAKERNEL) ? launch_megakernel(sc, cam, pr, map, d_out, stream)
-                                           : launch_wavefront(sc, cam, pr, map, d_out, stream);
+                                           : launch_wavefront(sc, cam, pr, map, d_out, stream, s_first, s_count);
     if (st != HRT_OK) return st;
     HIPCHK(hipEventRecord(b, stream));
     sc->pending.push_back({a, b});
@@ -1158,6 +1165,56 @@ hrt_status hrt_render_stripes_device(hrt_scene* sc, const hrt_camera* cam, const
     map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
     map.m_rw = fastdiv_magic((uint32_t)map.rw); map.m_nl = fastdiv_magic((uint32_t)map.rw * (uint32_t)map.rh);
     return launch_pathtrace(sc, cam, pr, map, d_out, (hipStream_t)stream);
+}
+
+hrt_status hrt_render_stripes_accumulate_device(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank,
+                                                int32_t G, float* d_accum, int32_t sample_first, int32_t sample_count, void* stream) {
+    if (!sc || !cam || !d_accum) return fail(HRT_ERR_INVALID, "NULL argument");
+    hrt_status st = check_params(pr);
+    if (st != HRT_OK) return st;
+    if (R <= 0 || G <= 0 || rank < 0 || rank >= G) return fail(HRT_ERR_INVALID, "bad stripe partition");
+    HIPCHK(hipSetDevice(sc->device));
+    RenderMap map{};
+    map.mode = 1; map.R = R; map.rank = rank; map.G = G;
+    map.rw = pr->width; map.rh = hrt_stripe_rows(pr->height, R, rank, G);
+    map.tiles_x = (map.rw + 7) / 8;
+    map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
+    map.m_rw = fastdiv_magic((uint32_t)map.rw); map.m_nl = fastdiv_magic((uint32_t)map.rw * (uint32_t)map.rh);
+    return launch_pathtrace(sc, cam, pr, map, d_accum, (hipStream_t)stream, sample_first, sample_count);
+}
+
+hrt_status hrt_render_stripes_accumulate(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank, int32_t G,
+                                         float* accum, int32_t sample_first, int32_t sample_count, hrt_stats* stats) {
+    if (!sc || !cam || !accum) return fail(HRT_ERR_INVALID, "NULL argument");
+    hrt_status st = check_params(pr);
+    if (st != HRT_OK) return st;
+    if (R <= 0 || G <= 0 || rank < 0 || rank >= G) return fail(HRT_ERR_INVALID, "bad stripe partition");
+    HIPCHK(hipSetDevice(sc->device));
+    hrt_stats prev;
+    st = hrt_scene_stats(sc, &prev);
+    if (st != HRT_OK) return st;
+    const size_t bytes = (size_t)hrt_stripe_rows(pr->height, R, rank, G) * pr->width * 3 * sizeof(float);
+    if (bytes) {
+        float* d = nullptr;
+        hipError_t e = hipMalloc((void**)&d, bytes);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (sample_first > 0) {
+            hipError_t e1 = hipMemcpy(d, accum, bytes, hipMemcpyHostToDevice);
+            if (e1 != hipSuccess) { (void)hipFree(d); return fail_hip(e1, "hipMemcpy H2D accumulation buffer"); }
+        }
+        st = hrt_render_stripes_accumulate_device(sc, cam, pr, R, rank, G, d, sample_first, sample_count, nullptr);
+        if (st == HRT_OK) {
+            hipError_t e2 = hipMemcpy(accum, d, bytes, hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) st = fail_hip(e2, "hipMemcpy D2H accumulation buffer");
+        }
+        (void)hipFree(d);
+        if (st != HRT_OK) return st;
+    }
+    hrt_stats now;
+    st = hrt_scene_stats(sc, &now);
+    if (st != HRT_OK) return st;
+    if (stats) *stats = now;
+    return HRT_OK;
 }
 
 hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {

@@ -6,6 +6,9 @@
 //     --gpus N   --seed S   --spp N   --size WxH   --quirks reference|fixed
 //     --assets DIR (search dir for meshes / textures)   --stats   --out FILE
 //     --make-assets DIR (write the procedural teapot.obj / marble_bust_01.obj / old_hall_4k.hdr and exit)
+//     --progressive N (take the samples in passes of N and rewrite the output image after every pass)
+//     --checkpoint FILE (store the accumulation buffer after every pass)   --resume (continue from that file)
+//     --max-passes K (stop after K passes; with --checkpoint the render can be resumed later)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +55,10 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next("--out");
         else if (a == "--stats") opt.stats = true;
         else if (a == "--make-assets") makeAssets = next("--make-assets");
+        else if (a == "--progressive") opt.pass_samples = std::atoi(next("--progressive"));
+        else if (a == "--checkpoint") opt.checkpoint = next("--checkpoint");
+        else if (a == "--resume") opt.resume = true;
+        else if (a == "--max-passes") opt.max_passes = std::atoi(next("--max-passes"));
         else if (!haveFile) { file = a; haveFile = true; }
     }
     if (!makeAssets.empty()) {
@@ -77,6 +84,8 @@ int main(int argc, char** argv) {
 
     printElapsed(("Loaded scene: " + file + "!").c_str(), start);
 
+    if (opt.resume && opt.checkpoint.empty()) { std::cerr << "--resume needs --checkpoint FILE" << std::endl; return 2; }
+    if (opt.pass_samples > 0) opt.on_pass = [&film](int) { film->outputFilm(); };   // preview image after every pass
     hrt_stats stats{};
     double seconds = 0.0;
     hrt_status st = render(NUM_THREADS, background, world, camera, film, opt, &stats, &seconds);

@@ -2,7 +2,9 @@
 // body is the MI355X path (flatten -> libhrt_hip.so) instead of the PSTL loop.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
+#include <string>
 
 #include "classes.h"
 
@@ -15,6 +17,16 @@ struct RenderOptions {
     uint64_t seed = 0;
     int max_depth = 50;                 // MAX_DEPTH (main.cpp:32)
     bool stats = false;                 // count box / triangle tests too
+    // Progressive rendering: samples are taken in passes of `pass_samples` (0 = all at once);
+    // after every pass but the last the film holds the preview (mean of the samples so far) and `on_pass`
+    // is called (the CLI rewrites the output image there).  With `checkpoint` set, the accumulation sums and
+    // the next sample index are stored after every pass; `resume` continues a render from such a file (any
+    // GPU count: the file holds whole-film rows).  The finished film is bit-identical however it was batched.
+    int pass_samples = 0;
+    int max_passes = 0;                 // > 0: stop after this many passes (the checkpoint continues the render later)
+    std::string checkpoint;
+    bool resume = false;
+    std::function<void(int samples_done)> on_pass;
 };
 
 // render() of main.cpp:81-140.  nThreads is accepted and unused, exactly as in

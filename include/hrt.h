@@ -273,6 +273,23 @@ hrt_status hrt_render_tile(hrt_scene* scene, const hrt_camera* cam, const hrt_pa
 hrt_status hrt_render_stripes_device(hrt_scene* scene, const hrt_camera* cam, const hrt_params* params,
                                      int32_t rows_per_block, int32_t rank, int32_t n_ranks, float* d_out_rgb_linear,
                                      void* stream);
+/* Progressive / resumable form (the reference's render() takes all samples of a pixel in one go,
+ * main.cpp:118-126).  Adds samples [sample_first, sample_first + sample_count) of params->samples to the
+ * accumulation buffer (same layout as hrt_render_stripes_device's output): it holds the running SUM of the samples'
+ * radiances, added in sample order.  sample_first == 0 starts a new accumulation (the buffer need not be
+ * cleared).  The call whose range reaches params->samples divides the sums by params->samples (main.cpp:126),
+ * after which the buffer is bit-identical to a one-shot render with the same params, however the samples
+ * were batched.  The buffer plus the next sample index is the whole checkpoint of a render: it can be copied out,
+ * stored, and continued later (the row layout depends on rows_per_block / rank / n_ranks only).  Between passes a
+ * preview is accum / samples_done.  Wavefront pipeline only: HRT_FLAG_MEGAKERNEL with a partial range is
+ * HRT_ERR_UNSUPPORTED. */
+hrt_status hrt_render_stripes_accumulate_device(hrt_scene* scene, const hrt_camera* cam, const hrt_params* params,
+                                                int32_t rows_per_block, int32_t rank, int32_t n_ranks, float* d_accum,
+                                                int32_t sample_first, int32_t sample_count, void* stream);
+/* Blocking host-buffer form: `accum` is uploaded first when sample_first > 0, and downloaded after the pass. */
+hrt_status hrt_render_stripes_accumulate(hrt_scene* scene, const hrt_camera* cam, const hrt_params* params,
+                                         int32_t rows_per_block, int32_t rank, int32_t n_ranks, float* accum,
+                                         int32_t sample_first, int32_t sample_count, hrt_stats* stats);
 /* Blocking host-buffer form of the above (used by the CLI's one-thread-per-GPU
  * scheduler): same row layout, output copied to the caller-owned HOST buffer. */
 hrt_status hrt_render_stripes(hrt_scene* scene, const hrt_camera* cam, const hrt_params* params, int32_t rows_per_block,

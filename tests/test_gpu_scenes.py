@@ -170,6 +170,47 @@ def test_device_pointer_stream_api_with_torch(built, assets, scenes_dir):
     dev.close()
 
 
+def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
+    """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
+    (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
+    sums / samples_done; bad ranges and the megakernel with a partial range are refused."""
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/material_zoo.yaml", assets)
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    W, H, spp, R = 72, 56, 16, 8
+    cam, p = hs.camera(W, H), api.default_params(W, H, spp)
+    full, _ = dev.render_tile(cam, p)
+    for G, batches in ((1, (5, 7, 4)), (2, (1, 15)), (3, (16,))):
+        film = np.zeros((H, W, 3), np.float32)
+        for rank in range(G):
+            rows = api.stripe_rows(H, R, rank, G)
+            accum = np.full((rows, W, 3), np.nan, np.float32)      # sample_first == 0 must not read it
+            s0 = 0
+            for n in batches:
+                st = dev.render_stripes_accumulate(cam, p, R, rank, G, accum, s0, n)
+                assert st.samples == rows * W * n
+                s0 += n
+                if s0 < spp:   # preview of a partial render: the mean of the first s0 samples = a render at s0 spp, exactly
+                    pp = api.default_params(W, H, s0)
+                    part, _ = dev.render_stripes(cam, pp, R, rank, G)
+                    assert np.array_equal(accum / np.float32(s0), part, equal_nan=True)
+                accum = accum.copy()                                 # a checkpoint is just this array + s0
+            idx = [api.stripe_row_index(H, R, rank, G, l) for l in range(rows)]
+            film[idx] = accum
+        assert np.array_equal(film.view(np.uint32), full.view(np.uint32)), f"G={G} batches={batches}"
+    accum = np.zeros((H, W, 3), np.float32)
+    for bad in ((-1, 4), (0, 0), (10, 7), (16, 1)):
+        with pytest.raises(api.HrtError) as e:
+            dev.render_stripes_accumulate(cam, p, R, 0, 1, accum, *bad)
+        assert e.value.status == api.HRT_ERR_INVALID
+    with pytest.raises(api.HrtError) as e:
+        dev.render_stripes_accumulate(cam, api.default_params(W, H, spp, megakernel=True), R, 0, 1, accum, 0, 8)
+    assert e.value.status == api.HRT_ERR_UNSUPPORTED
+    dev.render_stripes_accumulate(cam, api.default_params(W, H, spp, megakernel=True), R, 0, 1, accum, 0, spp)   # the full range is fine
+    assert np.array_equal(accum.view(np.uint32), full.view(np.uint32))
+    dev.close()
+
+
 FULL_SIZE = [  # BASELINE.json configs at their full FILM sizes; spp reduced where the config's spp would only repeat the same code path
     ("cornell_box.yaml", 640, 640, 256, "C2: 640x640x256, analytic primitives only"),
     ("teapot_scene.yaml", 1024, 1024, 256, "C3: 1024x1024x256 (sample-chunked: 268 M slots > the 48 M slot budget)"),
