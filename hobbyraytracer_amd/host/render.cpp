@@ -99,13 +99,14 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     const int R = opt.rows_per_block;
     std::vector<std::vector<float>> parts(G);
     for (int g = 0; g < G; ++g) parts[g].assign((size_t)hrt_stripe_rows(f.height, R, g, G) * f.width * 3, 0.0f);
-    std::vector<float>& lin = film->linear();
+    std::vector<float>& lin = film->linear();     // what the film shows: the preview mean, at the end the final mean
+    std::vector<float> sums(lin.size(), 0.0f);     // whole-film accumulation buffer (absolute row order)
     auto gather = [&]() {   // rank g's local row l is absolute row hrt_stripe_row_index(...)
         for (int g = 0; g < G; ++g) {
             const int rows = hrt_stripe_rows(f.height, R, g, G);
             for (int l = 0; l < rows; ++l) {
                 const int row = hrt_stripe_row_index(f.height, R, g, G, l);
-                std::memcpy(&lin[(size_t)row * f.width * 3], &parts[g][(size_t)l * f.width * 3], (size_t)f.width * 3 * sizeof(float));
+                std::memcpy(&sums[(size_t)row * f.width * 3], &parts[g][(size_t)l * f.width * 3], (size_t)f.width * 3 * sizeof(float));
             }
         }
     };
@@ -114,7 +115,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
             const int rows = hrt_stripe_rows(f.height, R, g, G);
             for (int l = 0; l < rows; ++l) {
                 const int row = hrt_stripe_row_index(f.height, R, g, G, l);
-                std::memcpy(&parts[g][(size_t)l * f.width * 3], &lin[(size_t)row * f.width * 3], (size_t)f.width * 3 * sizeof(float));
+                std::memcpy(&parts[g][(size_t)l * f.width * 3], &sums[(size_t)row * f.width * 3], (size_t)f.width * 3 * sizeof(float));
             }
         }
     };
@@ -124,7 +125,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     if (opt.resume) {
         Checkpoint ck;
         std::string why;
-        if (!readCheckpoint(opt.checkpoint, ck, lin, why)) { std::cerr << "\nresume: " << why << std::endl; cleanup(); return HRT_ERR_IO; }
+        if (!readCheckpoint(opt.checkpoint, ck, sums, why)) { std::cerr << "\nresume: " << why << std::endl; cleanup(); return HRT_ERR_IO; }
         if (ck.width != f.width || ck.height != f.height || ck.samples != f.samples || ck.seed != opt.seed || ck.quirks != opt.quirks ||
             ck.max_depth != opt.max_depth || ck.next_sample < 0 || ck.next_sample > f.samples) {
             std::cerr << "\nresume: " << opt.checkpoint << " belongs to a different render (film, samples, seed, quirks or depth differ)" << std::endl;
@@ -169,13 +170,12 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
         gather();
         if (!opt.checkpoint.empty()) {
             Checkpoint ck{f.width, f.height, f.samples, s_done, opt.seed, opt.quirks, opt.max_depth};
-            if (!writeCheckpoint(opt.checkpoint, ck, lin)) { std::cerr << "\ncannot write checkpoint " << opt.checkpoint << std::endl; cleanup(); return HRT_ERR_IO; }
+            if (!writeCheckpoint(opt.checkpoint, ck, sums)) { std::cerr << "\ncannot write checkpoint " << opt.checkpoint << std::endl; cleanup(); return HRT_ERR_IO; }
         }
         if (s_done < f.samples) {   // preview: mean of the samples so far
-            std::vector<float> preview(lin.size());
             const float k = static_cast<float>(s_done);
-            for (size_t i = 0; i < lin.size(); ++i) preview[i] = lin[i] / k;
-            st = hrt_resolve_u8(scenes[0], preview.data(), numPixels, film->getPixels());
+            for (size_t i = 0; i < lin.size(); ++i) lin[i] = sums[i] / k;
+            st = hrt_resolve_u8(scenes[0], lin.data(), numPixels, film->getPixels());
             if (st != HRT_OK) { std::cerr << "\nresolve failed: " << hrt_last_error() << std::endl; cleanup(); return st; }
             std::cout << "\rSamples rendered: " << s_done << "/" << f.samples << std::flush;
             if (opt.on_pass) opt.on_pass(s_done);
@@ -183,6 +183,11 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     }
     const auto t1 = std::chrono::high_resolution_clock::now();
     if (render_seconds) *render_seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (s_done >= f.samples) lin = sums;           // the last pass divided (main.cpp:126): the sums are the means now
+    else if (passes == 0) {                        // nothing rendered in this call (resume of a stopped render with --max-passes 0 ...)
+        const float k = static_cast<float>(s_done > 0 ? s_done : 1);
+        for (size_t i = 0; i < lin.size(); ++i) lin[i] = sums[i] / k;
+    }
     st = hrt_resolve_u8(scenes[0], lin.data(), numPixels, film->getPixels());
     if (st != HRT_OK) std::cerr << "\nresolve failed: " << hrt_last_error() << std::endl;
     std::cout << "\rPixels rendered: " << numPixels << "/" << numPixels << std::flush << "\n";
