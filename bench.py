@@ -107,7 +107,16 @@ def main():
     api.write_hall_hdr(os.path.join(tmp, "old_hall_4k.hdr"), 4096, 2048)
     if "bust" in args.scene:
         api.write_bust_obj(os.path.join(tmp, "marble_bust_01.obj"), 1.0)   # ~100k triangles (config C5)
-    hs = api.HostScene(os.path.join(ROOT, "tests", "golden", "scenes", args.scene), tmp)
+    # the loader prints the reference's console lines ("Loading scene: ...", scene.cpp) on stdout: keep stdout for the JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        hs = api.HostScene(os.path.join(ROOT, "tests", "golden", "scenes", args.scene), tmp)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     W, H, spp = args.width, args.height, args.spp
     cam = hs.camera(W, H)
     quirks = api.QUIRKS_REFERENCE if args.quirks == "reference" else api.QUIRKS_FIXED

@@ -13,7 +13,7 @@ for r in csv.DictReader(open(f)):
     if "k_wf" in n or "k_pathtrace" in n:
         ms=float(r["TotalDurationNs"])/1e6
         if "<true" not in n:   # 1 warmup + 3 timed frames run these kernels
-            short=n.split("(anonymous namespace)::")[-1].split("<")[0].split("(")[0]
+            import re; short=re.search(r"(k_wf_[a-z]+|k_pathtrace)", n).group(1)
             print("  %-22s calls %5s  %8.2f ms/frame"%(short, r["Calls"], ms/4.0)); tot+=ms/4.0
 print("$tag: sum %.2f ms/frame"%tot)
 PY

@@ -9,13 +9,13 @@ d=gpurun_out/pmc_${tag}_$(echo $ctrs | cksum | cut -d' ' -f1)
 rm -rf $d
 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $d.log 2>&1
 python3 - <<PY
-import csv,glob,json,os,collections
+import csv,glob,json,os,collections,re
 fs=glob.glob("$d/*/*_counter_collection.csv")
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
 for r in csv.DictReader(open(fs[0])):
     n=r["Kernel_Name"]
     if "<true" in n or not ("k_wf" in n or "k_pathtrace" in n): continue
-    k=n.split("(anonymous namespace)::")[-1].split("<")[0].split("(")[0]
+    k=re.search(r"(k_wf_[a-z]+|k_pathtrace)", n).group(1)
     acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
     calls[(k,r["Counter_Name"])]+=1
 out="gpurun_out/pmc_$tag.json"
