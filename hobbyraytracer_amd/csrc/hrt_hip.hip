@@ -241,6 +241,11 @@ struct WfBuf {
     unsigned* live;              // per task: live paths, at positions [k*T, k*T + live[k])
     unsigned* qn;                // per task: rays queued for the current mesh
     unsigned* heads;             // per (round, mesh): next task for k_wf_ext
+    // Segment counts, one cell per k_wf_shade wave, folded into DeviceCounters::rays by k_wf_reduce: one atomic per
+    // wave on the one counter costs 8192 same-address atomics = 93 us per launch (~88 per us, MI355X_MICROARCH
+    // "dequeue"), which was the floor of every round of a small tile (one rank's share of an 8-GPU frame).
+    unsigned long long* wave_rays;
+    unsigned n_wave_rays;
     unsigned T, n_tasks;
 };
 struct WfScene {                 // world-list split points (host-computed)
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_shade_prof[i], prof[i]);
 #endif
     const unsigned seg = wave_sum(n_seg);
-    if (lane == 0 && seg) atomicAdd(&counters->rays, (unsigned long long)seg);
+    if (lane == 0 && seg) w.wave_rays[wave] += (unsigned long long)seg;      // this wave's own cell: no contention
     if (STATS) {
         const unsigned mh = wave_sum(pc.mesh_hits), ev = wave_sum(pc.env_lookups), c = wave_sum(n_culled);
         if (lane == 0) {
@@ -672,7 +677,8 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
 
 // Per pixel: add the batch's samples IN SAMPLE ORDER (main.cpp:118-124); divide once all samples are in (main.cpp:126).
 __global__ __launch_bounds__(256) void k_wf_reduce(const float4* __restrict__ rad, unsigned n_local, int chunk, int first_chunk, int last_chunk,
-                                                   int spp, float* __restrict__ out, DeviceCounters* counters) {
+                                                   int spp, float* __restrict__ out, DeviceCounters* counters,
+                                                   unsigned long long* __restrict__ wave_rays, unsigned n_wave_rays) {
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned lp = blockIdx.x * blockDim.x + threadIdx.x; lp < n_local; lp += stride) {
         vec3 sum(0.0f);
@@ -684,7 +690,19 @@ __global__ __launch_bounds__(256) void k_wf_reduce(const float4* __restrict__ ra
         if (last_chunk) sum = sum / static_cast<float>(spp);
         out[3ull * lp] = sum.x; out[3ull * lp + 1] = sum.y; out[3ull * lp + 2] = sum.z;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->samples, (unsigned long long)n_local * (unsigned long long)chunk);
+    if (blockIdx.x == 0) {   // fold the per-wave segment counts of this batch's 50 k_wf_shade launches
+        __shared__ unsigned long long total;
+        if (threadIdx.x == 0) total = 0;
+        __syncthreads();
+        unsigned long long mine = 0;
+        for (unsigned i = threadIdx.x; i < n_wave_rays; i += blockDim.x) { mine += wave_rays[i]; wave_rays[i] = 0; }
+        if (mine) atomicAdd(&total, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (total) atomicAdd(&counters->rays, total);
+            atomicAdd(&counters->samples, (unsigned long long)n_local * (unsigned long long)chunk);
+        }
+    }
 }
 
 }  // namespace
@@ -893,7 +911,8 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * sizeof(float4));
     const size_t i4 = al(slots * sizeof(int));
-    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) + al(head_words * sizeof(unsigned));   // 184 B per slot
+    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) + al(head_words * sizeof(unsigned)) +
+                         al((size_t)sc->n_cus * 32 * sizeof(unsigned long long));                                      // 184 B per slot
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, total);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string("hipMalloc(wavefront workspace): ") + hipGetErrorString(e));
@@ -907,6 +926,9 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.heads = (unsigned*)take(al(head_words * sizeof(unsigned)));
+    w.buf.n_wave_rays = (unsigned)sc->n_cus * 8u * 4u;           // k_wf_shade never runs more waves (task_blocks <= 8 per CU, 4 waves each)
+    w.buf.wave_rays = (unsigned long long*)take(al((size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(w.buf.wave_rays, 0, (size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
     w.base = base; w.bytes = total; w.slots = slots; w.depth = depth; w.n_mesh = n_mesh;
     return HRT_OK;
 }
@@ -977,7 +999,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
             else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
         }
         const int rblocks = (int)std::min<size_t>((n_local + 255) / 256, (size_t)sc->n_cus * 8);
-        hipLaunchKernelGGL(k_wf_reduce, dim3(rblocks), dim3(256), 0, stream, w.rad, n_local, c, s0 == 0 ? 1 : 0, s0 + c >= pr->samples ? 1 : 0, pr->samples, d_out, sc->d_counters);
+        hipLaunchKernelGGL(k_wf_reduce, dim3(rblocks), dim3(256), 0, stream, w.rad, n_local, c, s0 == 0 ? 1 : 0, s0 + c >= pr->samples ? 1 : 0, pr->samples, d_out, sc->d_counters, w.wave_rays, w.n_wave_rays);
         HIPCHK(hipGetLastError());
     }
     return HRT_OK;
