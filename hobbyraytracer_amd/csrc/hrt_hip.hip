@@ -964,9 +964,15 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     for (int s0 = s_first; s0 < s_end; s0 += chunk) {
         const int c = std::min(chunk, s_end - s0);
         const unsigned n_slots = n_local * (unsigned)c;
-        // task size: ~64 tasks per CU so the tail is short, between 256 and 4096 positions, a multiple of 64
-        size_t T = (n_slots / ((size_t)sc->n_cus * 64) + 63) & ~(size_t)63;
-        T = std::min<size_t>(4096, std::max<size_t>(256, T));
+        // Task size (positions per task, a multiple of 64).  Large batches: ~64 tasks per CU, so that the strided static
+        // ownership averages over several tasks per wave.  Small batches (one rank's share of a multi-GPU frame): no
+        // more tasks than the ~4096 waves k_wf_shade keeps resident, but up to 1280 positions each -- in the late rounds
+        // a task's survivors then still fill whole 64-lane chunks and a round costs ~2 instead of ~4 dependent chunk
+        // passes (measured on the 1/8 share of the headline frame: 11.4 -> 10.2 ms; tests/tools/stripe_scaling.py).
+        auto round64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        const size_t t_large = round64(n_slots / ((size_t)sc->n_cus * 64));
+        const size_t t_small = std::min<size_t>(1280, std::max<size_t>(256, round64(n_slots / ((size_t)sc->n_cus * 16))));
+        size_t T = std::min<size_t>(4096, std::max(t_large, t_small));
         w.T = (unsigned)T;
         w.n_tasks = (unsigned)((n_slots + T - 1) / T);
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block

@@ -21,7 +21,7 @@ p = api.default_params(W, H, spp, timing=True)
 out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 t1 = None
-for G in (1, 2, 4, 8):
+for G in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8)):
     for rank in (0, G - 1):
         dev.render_stripes_device(cam, p, R, rank, G, out.data_ptr(), stream)
         torch.cuda.synchronize()
