@@ -240,7 +240,6 @@ struct WfBuf {
     float4* rad;                 // radiance of the finished path of each SLOT
     unsigned* live;              // per task: live paths, at positions [k*T, k*T + live[k])
     unsigned* qn;                // per task: rays queued for the current mesh
-    unsigned* heads;             // per (round, mesh): next task for k_wf_ext
     // Segment counts, one cell per k_wf_shade wave, folded into DeviceCounters::rays by k_wf_reduce: one atomic per
     // wave on the one counter costs 8192 same-address atomics = 93 us per launch (~88 per us, MI355X_MICROARCH
     // "dequeue"), which was the floor of every round of a small tile (one rank's share of an 8-GPU frame).
@@ -408,7 +407,7 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
 // DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
 // leave room for more resident blocks per CU (20 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
 template <bool STATS, int DEPTH>
-__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w, unsigned* head,
+__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w,
                                                       DeviceCounters* counters, int leaf_num) {
     __shared__ int s_stack[DEPTH * HRT_BLOCK];
     int* stack = s_stack + threadIdx.x;
@@ -907,11 +906,10 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     if (w.base && w.slots >= slots && w.depth >= depth && w.n_mesh == n_mesh) return HRT_OK;
     if (w.base) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(w.base); w = WfWorkspace(); }
     const size_t max_tasks = slots / 256 + 1;
-    const size_t head_words = (size_t)depth * (n_mesh > 0 ? n_mesh : 1);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * sizeof(float4));
     const size_t i4 = al(slots * sizeof(int));
-    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) + al(head_words * sizeof(unsigned)) +
+    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) +
                          al((size_t)sc->n_cus * 32 * sizeof(unsigned long long));                                      // 184 B per slot
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, total);
@@ -925,7 +923,6 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     w.buf.rad = (float4*)take(f4);
     w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
-    w.buf.heads = (unsigned*)take(al(head_words * sizeof(unsigned)));
     w.buf.n_wave_rays = (unsigned)sc->n_cus * 8u * 4u;           // k_wf_shade never runs more waves (task_blocks <= 8 per CU, 4 waves each)
     w.buf.wave_rays = (unsigned long long*)take(al((size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
     HIPCHK(hipMemset(w.buf.wave_rays, 0, (size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
@@ -953,7 +950,6 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     ws.has_mesh = n_mesh > 0;
     ws.first_mesh = n_mesh > 0 ? sc->mesh_prims.front() : sc->n_prims;
     ws.rest = n_mesh > 0 ? sc->mesh_prims.back() + 1 : sc->n_prims;
-    const size_t head_words = (size_t)D * (n_mesh > 0 ? n_mesh : 1);
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
     int ext_per_cu_env = 0;                              // experiments: k_wf_ext blocks per CU
     if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu_env = std::min(10, std::max(1, atoi(e)));
@@ -976,14 +972,12 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         w.T = (unsigned)T;
         w.n_tasks = (unsigned)((n_slots + T - 1) / T);
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
-        HIPCHK(hipMemsetAsync(w.heads, 0, head_words * sizeof(unsigned), stream));
         if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         else hipLaunchKernelGGL(k_wf_gen<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         for (int r = 0; r < D; ++r) {
             const int par = r & 1;
             for (int m = 0; m < n_mesh; ++m) {
                 const int mp = sc->mesh_prims[m];
-                unsigned* head = w.heads + (size_t)r * n_mesh + m;
                 if (m > 0) {   // further meshes: analytic prims between the meshes + preparation
                     const int p0 = sc->mesh_prims[m - 1] + 1;
                     if (stats) hipLaunchKernelGGL(k_wf_pre<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
@@ -995,7 +989,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 const int md = sc->mesh_depths[m];
                 const int variant = md <= 20 ? 20 : (md <= 24 ? 24 : 32);
                 const int ext_blocks = sc->n_cus * (ext_per_cu_env ? ext_per_cu_env : (variant == 32 ? 4 : 6));
-#define HRT_LAUNCH_EXT(S, D) hipLaunchKernelGGL((k_wf_ext<S, D>), dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, head, sc->d_counters, leaf_num)
+#define HRT_LAUNCH_EXT(S, D) hipLaunchKernelGGL((k_wf_ext<S, D>), dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, sc->d_counters, leaf_num)
                 if (stats) { if (variant == 20) HRT_LAUNCH_EXT(true, 20); else if (variant == 24) HRT_LAUNCH_EXT(true, 24); else HRT_LAUNCH_EXT(true, 32); }
                 else { if (variant == 20) HRT_LAUNCH_EXT(false, 20); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
 #undef HRT_LAUNCH_EXT
