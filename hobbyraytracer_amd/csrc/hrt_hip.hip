@@ -245,8 +245,62 @@ struct WfBuf {
     // "dequeue"), which was the floor of every round of a small tile (one rank's share of an 8-GPU frame).
     unsigned long long* wave_rays;
     unsigned n_wave_rays;
+    unsigned* task_ctr;          // THIS launch's HRT_TASK_GROUPS "next task" counters (zeroed once per batch)
+    unsigned n_groups;           // min(HRT_TASK_GROUPS, waves of this launch): every group has a wave
+    unsigned pull_k;             // tasks per pull
+    unsigned group_q, group_r;   // n_tasks / n_groups, n_tasks % n_groups
     unsigned T, n_tasks;
 };
+// Task ownership.  Tasks differ in cost by orders of magnitude (a run of pixels under the mesh vs. a run of sky), so a
+// static wave -> task map leaves most waves idle while a few finish: plain striding (task = wave + i * n_waves) even
+// resonates with the film -- n_waves x T is a whole number of images for power-of-two films (8192 waves x 4096 slots =
+// 8 x 2048^2), a wave then gets the same image region in every turn (C5 bust: traversal 307 -> 470 ms per frame when the
+// batches grew until T hit 4096).  One global "next task" counter is no answer either: same-address atomics retire at
+// ~88 per us on MI355X, 16000 tasks + 6000 waves = 0.25 ms per launch.  So: HRT_TASK_GROUPS counters; group g owns the
+// tasks g, g + G, g + 2G, ... (251 is prime: every group samples the whole film whatever its size) and its waves
+// (wave mod G == g, ~24 of them) pull from the group's counter -- balanced within a group by the pulls, across groups by
+// the interleaving, and ~100 atomics per address per launch.
+// A pull takes `pull_k` of the group's tasks at once (host: so that a wave pulls ~4 times per launch however many tasks
+// there are -- the atomic's round trip is ~2 us, which is the whole cost of a late round's nearly empty task), and a wave
+// that can see it took the group's last task does not pull again to find out.
+#define HRT_TASK_GROUPS 251
+// With no more tasks than waves (small batches: one rank's share of a multi-GPU frame) every wave simply takes the task of
+// its own number (pull_k == 0): nothing to balance, and the atomic's round trip would be added to every launch.
+struct TaskPuller { unsigned wave, g, next, end; };   // wave-uniform; the rest lives in the kernel arguments (registers are dear)
+// (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes, and would keep the walk in VGPRs)
+__device__ inline TaskPuller wf_task_puller(unsigned wave, unsigned n_groups) {
+    TaskPuller p;
+    p.wave = (unsigned)__builtin_amdgcn_readfirstlane((int)wave);
+    p.g = p.wave % n_groups; p.next = 0; p.end = 0;
+    return p;
+}
+#define HRT_TASK_PULLER(wave, n_groups) wf_task_puller((wave), (n_groups))
+template <class WF>
+__device__ inline bool wf_next_task(const WF& w, TaskPuller& p, unsigned lane, unsigned& task) {
+    if (w.pull_k == 0) {                                        // one task per wave at most
+        if (p.end != 0 || p.wave >= w.n_tasks) return false;
+        p.end = 1; task = p.wave;
+        return true;
+    }
+    if (p.next >= p.end) {
+        const unsigned mine = w.group_q + (p.g < w.group_r ? 1u : 0u);   // tasks of this group (no division here: registers)
+        if (p.end >= mine && p.end != 0) return false;         // this wave already holds the end of its group's list
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(&w.task_ctr[p.g], w.pull_k);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        p.next = k;
+        p.end = k + w.pull_k < mine ? k + w.pull_k : mine;      // clipped: next < end  <=>  a task of this group
+        if (p.end == 0) p.end = 1;                              // (group without tasks: the test above ends the walk)
+        if (k >= mine) { p.next = p.end; return false; }
+    }
+    task = p.next * w.n_groups + p.g;
+    ++p.next;
+    return true;
+}
+#define HRT_FOR_MY_TASKS(task, w, wave, lane)                       \
+    TaskPuller puller_ = HRT_TASK_PULLER((wave), (w).n_groups);     \
+    for (unsigned task = 0; wf_next_task((w), puller_, (lane), task);)
+
 struct WfScene {                 // world-list split points (host-computed)
     int first_mesh;              // index of the first HRT_PRIM_MESH, or n_prims when there is none
     int rest;                    // first prim after the last mesh (n_prims when there is no mesh)
@@ -325,7 +379,7 @@ __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_p
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned n_culled = 0;
-    for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
+    HRT_FOR_MY_TASKS(task, w, wave, lane) {
         const unsigned base = task * w.T;
         const unsigned n = base < n_slots ? min(w.T, n_slots - base) : 0u;
         unsigned qpos = base;
@@ -367,7 +421,7 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned n_culled = 0;
-    for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
+    HRT_FOR_MY_TASKS(task, w, wave, lane) {
         const unsigned base = task * w.T;
         const unsigned n = w.live[task];
         unsigned qpos = base;
@@ -424,7 +478,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     unsigned cur_pos = 0, cur_end = 0;   // wave-uniform: unread rays of the wave's current task
     bool wave_done = false;              // wave-uniform: no task left
     const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
-    unsigned next_task = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
+    TaskPuller puller = HRT_TASK_PULLER((blockIdx.x * blockDim.x + threadIdx.x) >> 6, w.n_groups);
     MeshRay r;
     TravState ts;
     ts.cur = HRT_TRAV_DONE;
@@ -440,11 +494,8 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
         const unsigned long long need = __ballot(!has);
         if (need && !wave_done) {
             while (cur_pos >= cur_end && !wave_done) {
-                // tasks are owned statically, strided over the waves of the grid: no atomic at all (a global
-                // task counter costs n_tasks + n_waves single-address atomics per launch, ~0.2 ms each time)
-                const unsigned t = next_task;
-                next_task += n_waves;
-                if (t >= w.n_tasks) wave_done = true;
+                unsigned t;
+                if (!wf_next_task(w, puller, lane, t)) wave_done = true;   // see HRT_TASK_GROUPS
                 else { cur_pos = t * w.T; cur_end = cur_pos + w.qn[t]; }
             }
             if (!wave_done) {
@@ -579,7 +630,7 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
 #endif
-    for (unsigned task = wave; task < w.n_tasks; task += n_waves) {
+    HRT_FOR_MY_TASKS(task, w, wave, lane) {
         const unsigned base = task * w.T;
         const unsigned n = w.live[task];
         unsigned out = base, qpos = base;
@@ -894,11 +945,23 @@ hrt_status launch_megakernel(hrt_scene* sc, const hrt_camera* cam, const hrt_par
     return HRT_OK;
 }
 
-size_t wf_max_slots() {
-    size_t cap = (size_t)48 << 20;                       // 48 Mi slots x 184 B = 8.6 GiB of the 288 GB
-    if (const char* e = getenv("HRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) cap = (size_t)v; }
-    return cap;
+// Most (pixel, sample) slots one batch may hold.  Every batch pays ~50 rounds x 2 kernels of fixed latency, so films
+// whose paths die early (open scenes: C4 shiny_teapot spends 22 batches at a 48 Mi cap, 141 ms; 2 batches, 91 ms) want
+// the largest batch that fits: 184 B per slot, up to 60 % of the free HBM (288 GB per MI355X) and 2^31 slots.  The
+// workspace is only ever as large as the batch needs (the headline frame: 41 M slots = 7.5 GB).
+size_t wf_max_slots(const hrt_scene* sc) {
+    if (const char* e = getenv("HRT_WF_MAX_SLOTS")) { long long v = atoll(e); if (v > 0) return (size_t)v; }
+    size_t cap = (size_t)48 << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        free_b += sc->wf.bytes;                          // what we hold already can be re-used
+        cap = std::max(cap, (size_t)((double)free_b * 0.6 / 184.0));
+    }
+    return std::min(cap, (size_t)1 << 31);
 }
+
+// "next task" counters: one block of 256 words per kernel launch of a batch (gen + per round: ext and pre per mesh, shade)
+size_t wf_counter_words(int depth, int n_mesh) { return (size_t)256 * (1 + (size_t)depth * (2 * (size_t)std::max(1, n_mesh) + 1)); }
 
 hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     WfWorkspace& w = sc->wf;
@@ -909,7 +972,8 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * sizeof(float4));
     const size_t i4 = al(slots * sizeof(int));
-    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) +
+    const size_t ctr_words = wf_counter_words(depth, n_mesh);
+    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) + al(ctr_words * sizeof(unsigned)) +
                          al((size_t)sc->n_cus * 32 * sizeof(unsigned long long));                                      // 184 B per slot
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, total);
@@ -923,6 +987,7 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     w.buf.rad = (float4*)take(f4);
     w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
+    w.buf.task_ctr = (unsigned*)take(al(ctr_words * sizeof(unsigned)));
     w.buf.n_wave_rays = (unsigned)sc->n_cus * 8u * 4u;           // k_wf_shade never runs more waves (task_blocks <= 8 per CU, 4 waves each)
     w.buf.wave_rays = (unsigned long long*)take(al((size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
     HIPCHK(hipMemset(w.buf.wave_rays, 0, (size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
@@ -938,12 +1003,17 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     const unsigned n_local = (unsigned)map.rw * (unsigned)map.rh;
     const int D = pr->max_depth;
     const int n_mesh = (int)sc->mesh_prims.size();
-    size_t cap = wf_max_slots();
+    size_t cap = wf_max_slots(sc);
     const int s_end = s_first + s_count;
     int chunk = (int)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local));
-    const size_t slots = (size_t)n_local * chunk;
-    if (slots >= ((size_t)1 << 32) - 4096) return fail(HRT_ERR_UNSUPPORTED, "tile too large for 32-bit slot ids");
-    hrt_status st = wf_reserve(sc, slots, D);
+    hrt_status st;
+    for (;;) {   // the memory estimate can be stale (other processes on the device): halve the batch on OOM
+        const size_t slots = (size_t)n_local * chunk;
+        if (slots >= ((size_t)1 << 32) - 4096) return fail(HRT_ERR_UNSUPPORTED, "tile too large for 32-bit slot ids");
+        st = wf_reserve(sc, slots, D);
+        if (st != HRT_ERR_OOM || chunk == 1) break;
+        chunk = (chunk + 1) / 2;
+    }
     if (st != HRT_OK) return st;
     WfBuf w = sc->wf.buf;
     WfScene ws;
@@ -972,6 +1042,17 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         w.T = (unsigned)T;
         w.n_tasks = (unsigned)((n_slots + T - 1) / T);
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
+        // every launch of the batch gets its own zeroed block of "next task" counters
+        unsigned* const ctr_base = sc->wf.buf.task_ctr;
+        HIPCHK(hipMemsetAsync(ctr_base, 0, wf_counter_words(D, n_mesh) * sizeof(unsigned), stream));
+        size_t launch_no = 0;
+        auto next_counters = [&](unsigned waves) {
+            w.task_ctr = ctr_base + 256 * launch_no++;
+            w.n_groups = std::min<unsigned>(HRT_TASK_GROUPS, waves);
+            w.pull_k = w.n_tasks <= waves ? 0u : std::min(32u, std::max(1u, w.n_tasks / (waves * 4u)));
+            w.group_q = w.n_tasks / w.n_groups; w.group_r = w.n_tasks % w.n_groups;
+        };
+        next_counters((unsigned)task_blocks * 4u);
         if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         else hipLaunchKernelGGL(k_wf_gen<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         for (int r = 0; r < D; ++r) {
@@ -980,6 +1061,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 const int mp = sc->mesh_prims[m];
                 if (m > 0) {   // further meshes: analytic prims between the meshes + preparation
                     const int p0 = sc->mesh_prims[m - 1] + 1;
+                    next_counters((unsigned)task_blocks * 4u);
                     if (stats) hipLaunchKernelGGL(k_wf_pre<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
                     else hipLaunchKernelGGL(k_wf_pre<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
                 }
@@ -989,12 +1071,14 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 const int md = sc->mesh_depths[m];
                 const int variant = md <= 20 ? 20 : (md <= 24 ? 24 : 32);
                 const int ext_blocks = sc->n_cus * (ext_per_cu_env ? ext_per_cu_env : (variant == 32 ? 4 : 6));
+                next_counters((unsigned)ext_blocks * (HRT_BLOCK / 64));
 #define HRT_LAUNCH_EXT(S, D) hipLaunchKernelGGL((k_wf_ext<S, D>), dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, sc->d_counters, leaf_num)
                 if (stats) { if (variant == 20) HRT_LAUNCH_EXT(true, 20); else if (variant == 24) HRT_LAUNCH_EXT(true, 24); else HRT_LAUNCH_EXT(true, 32); }
                 else { if (variant == 20) HRT_LAUNCH_EXT(false, 20); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
 #undef HRT_LAUNCH_EXT
                 if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
             }
+            next_counters((unsigned)task_blocks * 4u);
             if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
             else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
         }

@@ -213,7 +213,7 @@ def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
 
 FULL_SIZE = [  # BASELINE.json configs at their full FILM sizes; spp reduced where the config's spp would only repeat the same code path
     ("cornell_box.yaml", 640, 640, 256, "C2: 640x640x256, analytic primitives only"),
-    ("teapot_scene.yaml", 1024, 1024, 256, "C3: 1024x1024x256 (sample-chunked: 268 M slots > the 48 M slot budget)"),
+    ("teapot_scene.yaml", 1024, 1024, 256, "C3: 1024x1024x256 (268 M slots = 49 GB of wavefront state in one batch)"),
     ("shiny_teapot.yaml", 1920, 1080, 16, "C4 film 1920x1080 (512 spp in BASELINE; 16 here)"),
     ("bust_scene.yaml", 2048, 2048, 4, "C5 film 2048x2048 (1024 spp in BASELINE; 4 here)"),
 ]
