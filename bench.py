@@ -238,6 +238,9 @@ def main():
                          "box_tests_per_ray": round(st_count.box_tests / max(1, st_count.rays), 3),
                          "tri_tests_per_ray": round(st_count.tri_tests / max(1, st_count.rays), 3)},
         }
+        if roof_note is None and traffic and traffic < 0.5 * k_bytes:
+            roof_note = ("the BVH is L2-resident: measured HBM traffic is %.0f %% of the algorithmic bytes, so 'frac' prices L2-served bytes against "
+                         "the HBM peak and can exceed 1; the kernel is bound by instruction issue, not by HBM (DESIGN.md 4.1)" % (100.0 * traffic / k_bytes))
         if roof_note:
             result["roofline"]["note"] = roof_note
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
