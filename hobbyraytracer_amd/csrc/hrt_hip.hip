@@ -1046,10 +1046,11 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         unsigned* const ctr_base = sc->wf.buf.task_ctr;
         HIPCHK(hipMemsetAsync(ctr_base, 0, wf_counter_words(D, n_mesh) * sizeof(unsigned), stream));
         size_t launch_no = 0;
+        const bool force_dynamic = getenv("HRT_WF_DYNAMIC_TASKS") != nullptr;   // tests: exercise the pull path on small tiles too
         auto next_counters = [&](unsigned waves) {
             w.task_ctr = ctr_base + 256 * launch_no++;
             w.n_groups = std::min<unsigned>(HRT_TASK_GROUPS, waves);
-            w.pull_k = w.n_tasks <= waves ? 0u : std::min(32u, std::max(1u, w.n_tasks / (waves * 4u)));
+            w.pull_k = (w.n_tasks <= waves && !force_dynamic) ? 0u : std::min(32u, std::max(1u, w.n_tasks / (waves * 4u)));
             w.group_q = w.n_tasks / w.n_groups; w.group_r = w.n_tasks % w.n_groups;
         };
         next_counters((unsigned)task_blocks * 4u);

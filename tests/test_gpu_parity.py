@@ -187,7 +187,16 @@ def test_wavefront_sample_chunking_and_paths_agree(teapot, monkeypatch):
     monkeypatch.delenv("HRT_WF_MAX_SLOTS")
     assert np.array_equal(one.view(np.uint32), mega.view(np.uint32))
     assert np.array_equal(one.view(np.uint32), chunked.view(np.uint32))
-    for a in (s2, s3):
+    # task ownership (wave w takes task w on small tiles; pulls from the 251 group counters on large ones) cannot show
+    # in the result either: force the pull path on this small tile, alone and together with batching
+    monkeypatch.setenv("HRT_WF_DYNAMIC_TASKS", "1")
+    pulled, s4 = dev.render_tile(cam, api.default_params(W, H, spp, stats=True))
+    monkeypatch.setenv("HRT_WF_MAX_SLOTS", str(W * H * 4))
+    pulled_chunked, s5 = dev.render_tile(cam, api.default_params(W, H, spp, stats=True))
+    monkeypatch.delenv("HRT_WF_MAX_SLOTS"); monkeypatch.delenv("HRT_WF_DYNAMIC_TASKS")
+    assert np.array_equal(one.view(np.uint32), pulled.view(np.uint32))
+    assert np.array_equal(one.view(np.uint32), pulled_chunked.view(np.uint32))
+    for a in (s2, s3, s4, s5):
         assert (a.rays, a.samples, a.box_tests, a.tri_tests, a.mesh_hits, a.env_lookups) == \
                (s1.rays, s1.samples, s1.box_tests, s1.tri_tests, s1.mesh_hits, s1.env_lookups)
 
