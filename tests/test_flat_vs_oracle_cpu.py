@@ -11,6 +11,7 @@ SCENES = {  # name -> (W, H, spp)
     "cornell_box.yaml": (48, 48, 6),
     "bust_scene.yaml": (40, 40, 4),
     "material_zoo.yaml": (56, 56, 6),
+    "three_meshes.yaml": (60, 40, 4),      # several meshes interleaved with analytic prims in the world list
 }
 
 

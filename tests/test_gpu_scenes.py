@@ -11,6 +11,7 @@ SCENES = {  # name -> (W, H, spp)
     "cornell_box.yaml": (96, 96, 16),       # C2: rects, boxes (rotate_y / rotate wrappers), rough dielectric + metal spheres
     "bust_scene.yaml": (80, 80, 8),         # C5: dielectric mesh in one Translate, ConstantMedium (RNG inside hit), checker floor
     "material_zoo.yaml": (96, 96, 12),      # image / checker textures, pbr, uv_test, isotropic in a box, 3-wrapper mesh
+    "three_meshes.yaml": (96, 64, 8),       # three meshes (3 wrappers / 1 / none) interleaved with spheres and rects: k_wf_pre, one traversal per mesh
 }
 
 
