@@ -171,6 +171,45 @@ def test_device_pointer_stream_api_with_torch(built, assets, scenes_dir):
     dev.close()
 
 
+def test_world_larger_than_the_lds_tables(built, assets, tmp_path):
+    """150 spheres with 40 materials + a mesh: prims/materials no longer fit the 12 KB LDS staging area of the
+    kernels (hrt_device.h stage_tables), which then read them from global memory through the same pointers.
+    Same film as the oracle, both paths."""
+    import shutil
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    r = np.random.default_rng(12)
+    mats, objs = [], []
+    for i in range(40):
+        c = r.uniform(0.1, 0.9, 3)
+        kind = ("lambertian", "metal", "dielectric")[i % 3]
+        extra = {"lambertian": "", "metal": f"    roughness: {r.uniform(0, 0.5):.3f}\n", "dielectric": "    ior: 1.5\n"}[kind]
+        mats.append(f"  - name: m{i}\n    type: {kind}\n    albedo: [{c[0]:.3f}, {c[1]:.3f}, {c[2]:.3f}]\n{extra}")
+    for i in range(150):
+        x, z = r.uniform(-6, 6), r.uniform(-6, 4)
+        rad = r.uniform(0.15, 0.35)
+        objs.append(f"  - type: sphere\n    center: [{x:.3f}, {rad:.3f}, {z:.3f}]\n    radius: {rad:.3f}\n    material: m{i % 40}\n")
+    yaml = ("film:\n    width: 96\n    height: 64\n    samples: 6\n    output: many.png\n"
+            "camera:\n    position: [0, 2.5, 9]\n    look_at: [0, 0.5, 0]\n    up: [0, 1, 0]\n    fov: 40\n    aperture: 0\n    focal_distance: 9\n"
+            "    background: [0.6, 0.7, 0.9]\n"
+            "materials:\n  - name: ground\n    type: lambertian\n    albedo: [0.5, 0.5, 0.5]\n" + "".join(mats) +
+            "objects:\n  - type: xz_rect\n    x: [-8, 8]\n    z: [-8, 8]\n    k: 0\n    material: ground\n" + "".join(objs[:75]) +
+            "  - type: mesh\n    path: teapot.obj\n    material: m1\n    transform:\n        translate: [0, 0, -1]\n" + "".join(objs[75:]))
+    (tmp_path / "many.yaml").write_text(yaml)
+    shutil.copy(f"{assets}/teapot.obj", tmp_path / "teapot.obj")
+    hs = api.HostScene(str(tmp_path / "many.yaml"), str(tmp_path))
+    assert hs.flat.n_prims == 152 and hs.flat.n_prims * 136 > 12288
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    W, H, spp = 96, 64, 6
+    cam = hs.camera(W, H)
+    ref, sref = orc.World(hs.flat_ptr).render_tile(cam, api.default_params(W, H, spp, stats=True))
+    for mega in (False, True):
+        img, st = dev.render_tile(cam, api.default_params(W, H, spp, stats=True, megakernel=mega))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"megakernel={mega}"
+        assert (st.rays, st.samples, st.mesh_hits, st.env_lookups) == (sref.rays, sref.samples, sref.mesh_hits, sref.env_lookups)
+    dev.close()
+
+
 def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
     (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
