@@ -322,39 +322,21 @@ __device__ inline rng_ctx slot_ctx(const hrt_params& pr, const RenderMap& map, u
     return ctx;
 }
 
-#ifdef HRT_EXT_PROFILE   // debug variant only (build_variants/): where do the traversal waves spend their cycles?
-__device__ unsigned long long g_ext_prof[16];
-__device__ unsigned long long g_shade_prof[16];
-#define PROF_T(v) const long long v = clock64()
-#define PROF_ADD(i, x) prof[i] += (unsigned long long)(x)
-#else
-#define PROF_T(v)
-#define PROF_ADD(i, x)
-#endif
-
 // Preparation of one segment: analytic prims [p0, p1) in list order (closest-so-far semantics of
 // hittableList.cpp:12-19), then the ray in the space of mesh prim `mesh_prim` and the root-box filter.
 template <bool STATS>
 __device__ inline bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
-                                  const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled,
-                                  unsigned long long* prof = nullptr) {
-    PROF_T(q0);
+                                  const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled) {
     prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
     if (mesh_prim < 0) return false;
-    PROF_T(q1);
     const auto& mp = uniform_table(sc.prims)[mesh_prim];
     const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
     vec3 lo = o, ld = d;
     for (int k = 0; k < mp.n_xforms; ++k) xf_apply(mp.xf[k], lo, ld, pr.quirks);
-    PROF_T(q2);
     float4 grid_o, grid_s;
     mesh_grid(sc, mp.mesh, grid_o, grid_s);
     mr = mesh_ray_setup(lo, ld, pr.quirks, grid_o, grid_s);
-    PROF_T(q3);
     const bool enq = root_may_hit(sc, mesh, mr, trav_t_lo(pr.t_min, pr.quirks), closest);
-#ifdef HRT_EXT_PROFILE
-    { const long long q4 = clock64(); if (prof) { prof[10] += q1 - q0; prof[11] += q2 - q1; prof[12] += q3 - q2; prof[13] += q4 - q3; } }
-#endif
     if (STATS && !enq && mesh.node_count) n_culled++;
     return enq;
 }
@@ -413,42 +395,52 @@ __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_p
     }
 }
 
-// Scenes with several meshes: analytic prims [p0, mesh_prim) + preparation for mesh prim `mesh_prim`.
+// ---- the three per-round stages as WAVE-LEVEL functions over one task; the kernels below (one launch per stage per
+// ---- round, or k_wf_tail: every remaining round of a task in one go) only differ in how a wave comes by its tasks.
+
+// Scenes with several meshes: analytic prims [p0, mesh_prim) + preparation for mesh prim `mesh_prim`.  Returns the number
+// of rays queued for the traversal.
+template <bool STATS>
+__device__ inline unsigned wf_pre_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, unsigned n_local, int s0, int round, int par,
+                                       int p0, int mesh_prim, const WfBuf& w, unsigned task, unsigned n, unsigned lane, unsigned long long lt,
+                                       unsigned& n_culled) {
+    const unsigned base = task * w.T;
+    unsigned qpos = base;
+    for (unsigned j0 = 0; j0 < n; j0 += 64) {
+        const unsigned pos = base + j0 + lane;
+        bool enq = false;
+        MeshRay mr;
+        float closest = 0.0f;
+        if (j0 + lane < n) {
+            const float4 a = w.S0[par][pos], b = w.S1[par][pos];
+            const vec3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
+            closest = a.w;
+            int prim = __float_as_int(w.S2[par][pos].w), sub = w.S3[par][pos];
+            const int prim0 = prim;
+            const rng_ctx ctx = slot_ctx(pr, map, __float_as_uint(b.w), n_local, s0, round);
+            enq = wf_prepare<STATS>(sc, pr, p0, mesh_prim, mesh_prim, o, d, ctx, closest, prim, sub, mr, n_culled);
+            if (prim != prim0) {
+                ((float*)&w.S0[par][pos])[3] = closest;
+                ((float*)&w.S2[par][pos])[3] = __int_as_float(prim);
+                w.S3[par][pos] = sub;
+            }
+        }
+        const unsigned long long m = __ballot(enq);
+        if (enq) wf_store_record(w, qpos + (unsigned)__popcll(m & lt), mr, closest, pos);
+        qpos += (unsigned)__popcll(m);
+    }
+    return qpos - base;
+}
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, RenderMap map, unsigned n_local, int s0, int round, int par,
                                                 int p0, int mesh_prim, WfBuf w, DeviceCounters* counters) {
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned n_culled = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        const unsigned base = task * w.T;
-        const unsigned n = w.live[task];
-        unsigned qpos = base;
-        for (unsigned j0 = 0; j0 < n; j0 += 64) {
-            const unsigned pos = base + j0 + lane;
-            bool enq = false;
-            MeshRay mr;
-            float closest = 0.0f;
-            if (j0 + lane < n) {
-                const float4 a = w.S0[par][pos], b = w.S1[par][pos];
-                const vec3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
-                closest = a.w;
-                int prim = __float_as_int(w.S2[par][pos].w), sub = w.S3[par][pos];
-                const int prim0 = prim;
-                const rng_ctx ctx = slot_ctx(pr, map, __float_as_uint(b.w), n_local, s0, round);
-                enq = wf_prepare<STATS>(sc, pr, p0, mesh_prim, mesh_prim, o, d, ctx, closest, prim, sub, mr, n_culled);
-                if (prim != prim0) {
-                    ((float*)&w.S0[par][pos])[3] = closest;
-                    ((float*)&w.S2[par][pos])[3] = __int_as_float(prim);
-                    w.S3[par][pos] = sub;
-                }
-            }
-            const unsigned long long m = __ballot(enq);
-            if (enq) wf_store_record(w, qpos + (unsigned)__popcll(m & lt), mr, closest, pos);
-            qpos += (unsigned)__popcll(m);
-        }
-        if (lane == 0) w.qn[task] = qpos - base;
+        const unsigned qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, round, par, p0, mesh_prim, w, task, w.live[task], lane, lt, n_culled);
+        if (lane == 0) w.qn[task] = qn;
     }
     if (STATS) {
         const unsigned c = wave_sum(n_culled);
@@ -456,48 +448,44 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
     }
 }
 
-// Persistent BVH traversal of the queued rays of one mesh prim.  A wave walks its tasks (strided static
-// ownership) and hands their rays to its lanes as they fall idle (ballot + prefix count, no atomics).
-// DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
-// leave room for more resident blocks per CU (20 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
-template <bool STATS, int DEPTH>
-__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w,
-                                                      DeviceCounters* counters, int leaf_num) {
-    __shared__ int s_stack[DEPTH * HRT_BLOCK];
-    int* stack = s_stack + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const hrt_mesh mesh = sc.meshes[sc.prims[mesh_prim].mesh];
-    const uint4* nodes = sc.qnodes + 2ull * mesh.node_first;
-    const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
-    const float4* tbox = sc.tri_box + 2ull * mesh.tri_first;
+// BVH traversal of queued rays of one mesh prim by one wave.  `next_range(first, end)` hands the wave its next run of
+// ray records (a task's queue) or returns false; finished lanes pull the next ray of the run (ballot + prefix count).
+// While-while with postponed leaves: inner nodes are walked (two steps per wave vote: the ballots, counts, compare and
+// branch are a third of a step's instructions) until at least leaf_num/64 of the busy lanes stand at a leaf -- waiting for
+// ALL of them would run the loop at the pace of the slowest lane -- then the leaves are tested together; lanes still at an
+// inner node sit the leaf phase out.
+struct ExtMesh {                 // wave-uniform per-mesh constants of the traversal
+    const uint4* nodes; const float4* tpos; const float4* tbox;
     float4 grid_o, grid_s;
-    mesh_grid(sc, sc.prims[mesh_prim].mesh, grid_o, grid_s);
+    uint32_t node_count;
+};
+__device__ inline ExtMesh wf_ext_mesh(const DScene& sc, int mesh_prim) {
+    ExtMesh m;
+    const auto& mp = uniform_table(sc.prims)[mesh_prim];
+    const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
+    m.nodes = sc.qnodes + 2ull * mesh.node_first;
+    m.tpos = sc.tri_pos + 3ull * mesh.tri_first;
+    m.tbox = sc.tri_box + 2ull * mesh.tri_first;
+    mesh_grid(sc, mp.mesh, m.grid_o, m.grid_s);
+    m.node_count = mesh.node_count;
+    return m;
+}
+template <bool STATS, class NextRange>
+__device__ inline void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, int* stack, unsigned lane,
+                                  unsigned long long lt, int leaf_num, DCounters& cnt, NextRange next_range) {
     const float t_lo = trav_t_lo(pr.t_min, pr.quirks);
     bool has = false;
-    unsigned cur_pos = 0, cur_end = 0;   // wave-uniform: unread rays of the wave's current task
-    bool wave_done = false;              // wave-uniform: no task left
-    const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
-    TaskPuller puller = HRT_TASK_PULLER((blockIdx.x * blockDim.x + threadIdx.x) >> 6, w.n_groups);
+    unsigned cur_pos = 0, cur_end = 0;   // wave-uniform: unread rays of the current run
+    bool wave_done = false;              // wave-uniform: no run left
     MeshRay r;
     TravState ts;
     ts.cur = HRT_TRAV_DONE;
     unsigned pos = 0;
-    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
-#ifdef HRT_EXT_PROFILE
-    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const long long t_begin = clock64();
-    unsigned my_steps = 0;
-#endif
     for (;;) {
-        PROF_T(t0);
         const unsigned long long need = __ballot(!has);
         if (need && !wave_done) {
-            while (cur_pos >= cur_end && !wave_done) {
-                unsigned t;
-                if (!wf_next_task(w, puller, lane, t)) wave_done = true;   // see HRT_TASK_GROUPS
-                else { cur_pos = t * w.T; cur_end = cur_pos + w.qn[t]; }
-            }
+            while (cur_pos >= cur_end && !wave_done)
+                if (!next_range(cur_pos, cur_end)) wave_done = true;
             if (!wave_done) {
                 const unsigned q = cur_pos + (unsigned)__popcll(need & lt);
                 if (!has && q < cur_end) {
@@ -505,13 +493,13 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
                     r.o = vec3(e0.x, e0.y, e0.z); r.d = vec3(e1.x, e1.y, e1.z);
                     r.tr.o = r.o; r.tr.sX = e2.x; r.tr.sY = e2.y; r.tr.sZ = e2.z; r.tr.kZ = __float_as_int(e2.w);
                     r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
-                    mesh_ray_grid(r, grid_o, grid_s);
+                    mesh_ray_grid(r, em.grid_o, em.grid_s);
                     pos = __float_as_uint(e1.w);
-                    trav_init(ts, mesh, e0.w);
+                    ts.closest = e0.w; ts.best = -1;
+                    ts.selfhit = false; ts.self_order = 0xffffffffu; ts.self_tri = -1; ts.self_t = 0.0f;
+                    ts.sp = 0;
+                    ts.cur = em.node_count == 0 ? HRT_TRAV_DONE : 0;
                     has = true;
-#ifdef HRT_EXT_PROFILE
-                    my_steps = 0;
-#endif
                 }
                 cur_pos += (unsigned)__popcll(need);
             }
@@ -520,40 +508,17 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
             if (wave_done) break;
             continue;
         }
-        PROF_T(t1); PROF_ADD(0, t1 - t0);
-        // while-while with postponed leaves: walk inner nodes until at least leaf_num/64 of the wave's
-        // busy lanes stand at a leaf (waiting for ALL of them would run the loop at the pace of the slowest
-        // lane), then test the leaves together.  Lanes still at an inner node sit the leaf phase out; idle
-        // lanes are refilled at the top of the next round.
         for (;;) {
             const unsigned long long m_in = __ballot(has && trav_at_inner(ts));
             if (!m_in) break;
             const int n_leaf = __popcll(__ballot(has && trav_at_leaf(ts)));
             if (n_leaf * 64 >= leaf_num * (n_leaf + __popcll(m_in))) break;
-            PROF_ADD(3, 1); PROF_ADD(4, __popcll(m_in));
-            // two node steps per vote: the wave-level bookkeeping (two ballots, counts, compare, branch) is a
-            // third of a step's instructions
-#ifdef HRT_EXT_PROFILE
-            if (has && trav_at_inner(ts)) my_steps++;
-#endif
-            if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
-#ifdef HRT_EXT_PROFILE
-            if (has && trav_at_inner(ts)) my_steps++;
-#endif
-            if (has && trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
+            if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt);
+            if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt);
         }
-        PROF_T(t2); PROF_ADD(1, t2 - t1);
-        PROF_ADD(5, 1); PROF_ADD(6, __popcll(__ballot(has && trav_at_leaf(ts)))); PROF_ADD(7, __popcll(__ballot(has)));
         if (has) {
-            if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
+            if (trav_at_leaf(ts)) trav_leaf<STATS>(em.tpos, em.tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
             if (ts.cur == HRT_TRAV_DONE) {
-#ifdef HRT_EXT_PROFILE
-                {
-                    const unsigned long long dn = __ballot(true);
-                    prof[10] += __popcll(dn); prof[11] += __popcll(__ballot(my_steps <= 2)); prof[12] += __popcll(__ballot(my_steps <= 4));
-                    prof[13] += __popcll(__ballot(my_steps <= 8)); prof[14] += __popcll(__ballot(trav_result(ts, *(float*)&my_steps) >= 0));
-                }
-#endif
                 float t;
                 const int tri = trav_result(ts, t);
                 if (tri >= 0) {
@@ -564,12 +529,26 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
                 has = false;
             }
         }
-        PROF_T(t3); PROF_ADD(2, t3 - t2);
     }
-#ifdef HRT_EXT_PROFILE
-    prof[8] = (unsigned long long)(clock64() - t_begin); prof[9] = 1;
-    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_ext_prof[i], prof[i]);
-#endif
+}
+// One launch per round and mesh: persistent waves pull tasks (HRT_TASK_GROUPS) and their rays.
+// DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
+// leave room for more resident blocks per CU (20 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
+template <bool STATS, int DEPTH>
+__global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w,
+                                                      DeviceCounters* counters, int leaf_num) {
+    __shared__ int s_stack[DEPTH * HRT_BLOCK];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const ExtMesh em = wf_ext_mesh(sc, mesh_prim);
+    TaskPuller puller = HRT_TASK_PULLER((blockIdx.x * blockDim.x + threadIdx.x) >> 6, w.n_groups);
+    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+    wf_ext_run<STATS>(em, pr, mesh_prim, par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
+        unsigned t;
+        if (!wf_next_task(w, puller, lane, t)) return false;
+        first = t * w.T; end = first + w.qn[t];
+        return true;
+    });
     if (STATS) {
         const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
         if (lane == 0) {
@@ -606,113 +585,80 @@ __device__ inline void missq_flush(const DScene& sc, const WfBuf& w, MissQueue& 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// The rest of the segment (analytic prims behind the last mesh, main.cpp:46-76) for every live path, and,
-// for the survivors, the preparation of their next segment.  Survivors are written compacted, in order,
-// to the other state copy.
-#ifndef HRT_SHADE_WAVES
-#define HRT_SHADE_WAVES 4   // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
-#endif
+// The rest of the segment (analytic prims behind the last mesh, main.cpp:46-76) for every live path of one task, and,
+// for the survivors, the preparation of their next segment.  Survivors are written compacted, in order, to the other
+// state copy.  n = live paths of the task; returns the survivors (live_out) and the rays queued for the first mesh (qn_out).
 template <bool STATS>
-__global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hrt_params pr, RenderMap map, WfScene ws, unsigned n_local, int s0, int round,
-                                                  WfBuf w, DeviceCounters* counters) {
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+__device__ inline void wf_shade_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, const WfScene& ws, unsigned n_local, int s0, int round,
+                                     const WfBuf& w, unsigned task, unsigned n, unsigned lane, unsigned long long lt, MissQueue& mq,
+                                     PathCounters& pc, unsigned& n_seg, unsigned& n_culled, unsigned& live_out, unsigned& qn_out) {
     const int par = round & 1, nxt = par ^ 1;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
-    __shared__ float s_missq[4][7 * HRT_MISSQ_CAP];
-    stage_tables(sc, s_tables);
-    MissQueue mq;
-    mq.f = s_missq[threadIdx.x >> 6]; mq.slot = (unsigned*)(mq.f + 6 * HRT_MISSQ_CAP); mq.count = 0;
-    unsigned n_seg = 0, n_culled = 0;
-    PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
-#ifdef HRT_EXT_PROFILE
-    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const long long t_begin = clock64();
-#endif
-    HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        const unsigned base = task * w.T;
-        const unsigned n = w.live[task];
-        unsigned out = base, qpos = base;
-        for (unsigned j0 = 0; j0 < n; j0 += 64) {
-            const unsigned pos = base + j0 + lane;
-            float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-            int sub0 = -1;
-            PROF_T(t0);
-            if (j0 + lane < n) { a = w.S0[par][pos]; b = w.S1[par][pos]; c = w.S2[par][pos]; sub0 = w.S3[par][pos]; }
-#ifdef HRT_EXT_PROFILE
-            if (__float_as_uint(a.x) == 0x7fc12345u && sub0 == 0x7eadbeef) prof[15]++;   // force the loads to complete here
-#endif
-            PROF_T(t1); PROF_ADD(0, t1 - t0); PROF_ADD(5, 1); PROF_ADD(6, __popcll(__ballot(j0 + lane < n)));
-            bool alive = false;
-            PathState ps;
-            unsigned slot = 0;
-            rng_ctx ctx; ctx.seed_lo = 0; ctx.seed_hi = 0; ctx.pixel = 0; ctx.sample = 0; ctx.bounce = 0;
-            bool missed = false;
-            WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = 0.0f;
-            if (j0 + lane < n) {
-                n_seg++;
-                ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(b.x, b.y, b.z);
-                ps.atten = vec3(c.x, c.y, c.z); ps.result = vec3(0.0f); ps.bounce = round;
-                slot = __float_as_uint(b.w);
-                float closest = a.w;
-                int prim = __float_as_int(c.w), sub = sub0;
-                ctx = slot_ctx(pr, map, slot, n_local, s0, round);
-                prims_range_hit(sc, ws.rest, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
-                wh.prim = prim; wh.sub = sub; wh.t = closest;
-                missed = prim < 0;
-            }
-            PROF_T(t2); PROF_ADD(1, t2 - t1);
-            {   // escaped paths: queue them; evaluate the background 64 at a time
-                const unsigned long long mm = __ballot(missed);
-                if (mm) {
-                    if (missed) {
-                        const unsigned e = mq.count + (unsigned)__popcll(mm & lt);
-                        mq.f[0 * HRT_MISSQ_CAP + e] = ps.d.x; mq.f[1 * HRT_MISSQ_CAP + e] = ps.d.y; mq.f[2 * HRT_MISSQ_CAP + e] = ps.d.z;
-                        mq.f[3 * HRT_MISSQ_CAP + e] = ps.atten.x; mq.f[4 * HRT_MISSQ_CAP + e] = ps.atten.y; mq.f[5 * HRT_MISSQ_CAP + e] = ps.atten.z;
-                        mq.slot[e] = slot;
-                    }
-                    mq.count += (unsigned)__popcll(mm);       // <= 63 + 64 < HRT_MISSQ_CAP
-                    if (mq.count >= 64) missq_flush<STATS>(sc, w, mq, lane, 64, pc);
-                }
-            }
-            if (j0 + lane < n && !missed) {
-                const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
-                if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
-                else alive = true;
-            }
-            PROF_T(t3); PROF_ADD(2, t3 - t2);
-            PROF_T(t4);
-            const unsigned long long ma = __ballot(alive);
-            PROF_ADD(7, __popcll(ma));
-            bool enq = false;
-            MeshRay mr;
-            float closest = __builtin_huge_valf();
-            unsigned npos = 0;
-            if (alive) {
-                npos = out + (unsigned)__popcll(ma & lt);
-                int prim = -1, sub = -1;
-                ctx.bounce = (uint32_t)(round + 1);   // the next segment's draws (ConstantMedium::hit inside wf_prepare)
-#ifdef HRT_EXT_PROFILE
-                enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled, prof);
-#else
-                enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
-#endif
-                wf_store_state(w, nxt, npos, ps, closest, slot, prim, sub);
-            }
-            out += (unsigned)__popcll(ma);
-            const unsigned long long me = __ballot(enq);
-            if (enq) wf_store_record(w, qpos + (unsigned)__popcll(me & lt), mr, closest, npos);
-            qpos += (unsigned)__popcll(me);
-            PROF_T(t5); PROF_ADD(3, t5 - t4);
+    const unsigned base = task * w.T;
+    unsigned out = base, qpos = base;
+    for (unsigned j0 = 0; j0 < n; j0 += 64) {
+        const unsigned pos = base + j0 + lane;
+        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+        int sub0 = -1;
+        if (j0 + lane < n) { a = w.S0[par][pos]; b = w.S1[par][pos]; c = w.S2[par][pos]; sub0 = w.S3[par][pos]; }
+        bool alive = false;
+        PathState ps;
+        unsigned slot = 0;
+        rng_ctx ctx; ctx.seed_lo = 0; ctx.seed_hi = 0; ctx.pixel = 0; ctx.sample = 0; ctx.bounce = 0;
+        bool missed = false;
+        WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = 0.0f;
+        if (j0 + lane < n) {
+            n_seg++;
+            ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(b.x, b.y, b.z);
+            ps.atten = vec3(c.x, c.y, c.z); ps.result = vec3(0.0f); ps.bounce = round;
+            slot = __float_as_uint(b.w);
+            float closest = a.w;
+            int prim = __float_as_int(c.w), sub = sub0;
+            ctx = slot_ctx(pr, map, slot, n_local, s0, round);
+            prims_range_hit(sc, ws.rest, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
+            wh.prim = prim; wh.sub = sub; wh.t = closest;
+            missed = prim < 0;
         }
-        if (lane == 0) { w.live[task] = out - base; w.qn[task] = qpos - base; }
+        {   // escaped paths: queue them; evaluate the background 64 at a time
+            const unsigned long long mm = __ballot(missed);
+            if (mm) {
+                if (missed) {
+                    const unsigned e = mq.count + (unsigned)__popcll(mm & lt);
+                    mq.f[0 * HRT_MISSQ_CAP + e] = ps.d.x; mq.f[1 * HRT_MISSQ_CAP + e] = ps.d.y; mq.f[2 * HRT_MISSQ_CAP + e] = ps.d.z;
+                    mq.f[3 * HRT_MISSQ_CAP + e] = ps.atten.x; mq.f[4 * HRT_MISSQ_CAP + e] = ps.atten.y; mq.f[5 * HRT_MISSQ_CAP + e] = ps.atten.z;
+                    mq.slot[e] = slot;
+                }
+                mq.count += (unsigned)__popcll(mm);       // <= 63 + 64 < HRT_MISSQ_CAP
+                if (mq.count >= 64) missq_flush<STATS>(sc, w, mq, lane, 64, pc);
+            }
+        }
+        if (j0 + lane < n && !missed) {
+            const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
+            if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
+            else alive = true;
+        }
+        const unsigned long long ma = __ballot(alive);
+        bool enq = false;
+        MeshRay mr;
+        float closest = __builtin_huge_valf();
+        unsigned npos = 0;
+        if (alive) {
+            npos = out + (unsigned)__popcll(ma & lt);
+            int prim = -1, sub = -1;
+            ctx.bounce = (uint32_t)(round + 1);   // the next segment's draws (ConstantMedium::hit inside wf_prepare)
+            enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
+            wf_store_state(w, nxt, npos, ps, closest, slot, prim, sub);
+        }
+        out += (unsigned)__popcll(ma);
+        const unsigned long long me = __ballot(enq);
+        if (enq) wf_store_record(w, qpos + (unsigned)__popcll(me & lt), mr, closest, npos);
+        qpos += (unsigned)__popcll(me);
     }
-    if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
-#ifdef HRT_EXT_PROFILE
-    prof[8] = (unsigned long long)(clock64() - t_begin); prof[9] = 1;
-    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_shade_prof[i], prof[i]);
-#endif
+    live_out = out - base; qn_out = qpos - base;
+}
+// what a shading wave adds to the device counters when it is done
+template <bool STATS>
+__device__ inline void wf_shade_counters(const WfBuf& w, DeviceCounters* counters, unsigned wave, unsigned lane, unsigned n_seg, unsigned n_culled,
+                                         const PathCounters& pc) {
     const unsigned seg = wave_sum(n_seg);
     if (lane == 0 && seg) w.wave_rays[wave] += (unsigned long long)seg;      // this wave's own cell: no contention
     if (STATS) {
@@ -723,6 +669,30 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
             if (c) atomicAdd(&counters->box_tests, 2ull * c);
         }
     }
+}
+#ifndef HRT_SHADE_WAVES
+#define HRT_SHADE_WAVES 4   // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
+#endif
+template <bool STATS>
+__global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hrt_params pr, RenderMap map, WfScene ws, unsigned n_local, int s0, int round,
+                                                  WfBuf w, DeviceCounters* counters) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
+    __shared__ float s_missq[4][7 * HRT_MISSQ_CAP];
+    stage_tables(sc, s_tables);
+    MissQueue mq;
+    mq.f = s_missq[threadIdx.x >> 6]; mq.slot = (unsigned*)(mq.f + 6 * HRT_MISSQ_CAP); mq.count = 0;
+    unsigned n_seg = 0, n_culled = 0;
+    PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
+    HRT_FOR_MY_TASKS(task, w, wave, lane) {
+        unsigned live, qn;
+        wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, round, w, task, w.live[task], lane, lt, mq, pc, n_seg, n_culled, live, qn);
+        if (lane == 0) { w.live[task] = live; w.qn[task] = qn; }
+    }
+    if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
+    wf_shade_counters<STATS>(w, counters, wave, lane, n_seg, n_culled, pc);
 }
 
 // Per pixel: add the batch's samples IN SAMPLE ORDER (main.cpp:118-124); divide once all samples are in (main.cpp:126).
@@ -1335,26 +1305,6 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
     stats->rays = c.rays; stats->samples = c.samples; stats->box_tests = c.box_tests; stats->tri_tests = c.tri_tests;
     stats->mesh_hits = c.mesh_hits; stats->env_lookups = c.env_lookups;
-#ifdef HRT_EXT_PROFILE
-    {
-        unsigned long long h[16], z[16] = {0};
-        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ext_prof), sizeof(h)));
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ext_prof), z, sizeof(z)));
-        fprintf(stderr, "[ext-prof] waves %llu  cycles/wave %.0f : refill %.1f%% inner %.1f%% leaf %.1f%% | inner iters/wave %.0f lanes/iter %.1f | leaf phases/wave %.0f leaf-lanes %.1f busy-lanes %.1f\n",
-                h[9], (double)h[8] / (h[9] ? h[9] : 1), 100.0 * h[0] / (h[8] ? h[8] : 1), 100.0 * h[1] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[8] ? h[8] : 1),
-                (double)h[3] / (h[9] ? h[9] : 1), (double)h[4] / (h[3] ? h[3] : 1), (double)h[5] / (h[9] ? h[9] : 1), (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / (h[5] ? h[5] : 1));
-        fprintf(stderr, "[ext-prof] rays %llu : <=2 node steps %.1f%%  <=4 %.1f%%  <=8 %.1f%%  hit a triangle %.1f%%\n", h[10], 100.0 * h[11] / (h[10] ? h[10] : 1),
-                100.0 * h[12] / (h[10] ? h[10] : 1), 100.0 * h[13] / (h[10] ? h[10] : 1), 100.0 * h[14] / (h[10] ? h[10] : 1));
-        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_prof), sizeof(h)));
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, sizeof(z)));
-        const double tot = (double)(h[8] ? h[8] : 1);
-        fprintf(stderr, "[shade-prof] waves %llu cycles/wave %.0f : load %.1f%% prims %.1f%% shade %.1f%% prepare+store %.1f%% | chunks/wave %.1f lanes %.1f alive %.1f\n",
-                h[9], tot / (h[9] ? h[9] : 1), 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot,
-                (double)h[5] / (h[9] ? h[9] : 1), (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / (h[5] ? h[5] : 1));
-        fprintf(stderr, "[shade-prof] inside prepare: analytic prims %.1f%% xforms %.1f%% ray setup %.1f%% root test %.1f%%\n",
-                100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot, 100.0 * h[13] / tot);
-    }
-#endif
     stats->kernel_ms = sc->kernel_ms; stats->launches = sc->launches;
     stats->traversal_ms = sc->traversal_ms; stats->traversal_launches = sc->traversal_launches;
     sc->kernel_ms = 0.0; sc->launches = 0; sc->traversal_ms = 0.0; sc->traversal_launches = 0;
