@@ -192,7 +192,8 @@ def main():
                 roof_note = "no mesh in this scene: the frame moves almost no memory, an HBM fraction is not meaningful (VALU / divergence bound)"
         else:
             kname, k_launches = "k_wf_ext", st.traversal_launches / max(1, st.launches)
-            k_bytes = (32.0 * st_count.box_tests + 36.0 * st_count.tri_tests) / k_launches
+            # bytes of exactly those launches (rounds a small batch runs inside k_wf_tail are neither timed nor counted here)
+            k_bytes = (32.0 * st_count.traversal_box_tests + 36.0 * st_count.traversal_tri_tests) / k_launches
             k_ms = st.traversal_ms / st.traversal_launches
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         # HBM traffic per launch of that kernel cannot be measured inside this process (PMC counters need their

@@ -100,7 +100,8 @@ class Rect(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("mesh_hits", C.c_uint64), ("env_lookups", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64),
-                ("traversal_ms", C.c_double), ("traversal_launches", C.c_uint64)]
+                ("traversal_ms", C.c_double), ("traversal_launches", C.c_uint64),
+                ("traversal_box_tests", C.c_uint64), ("traversal_tri_tests", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

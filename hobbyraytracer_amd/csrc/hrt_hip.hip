@@ -56,6 +56,7 @@ inline uint64_t fastdiv_magic(uint32_t d) { return d <= 1 ? 0 : (uint64_t)(~0ull
 
 struct DeviceCounters {      // 64-bit accumulators in device memory
     unsigned long long rays, samples, box_tests, tri_tests, mesh_hits, env_lookups;
+    unsigned long long trav_box_tests, trav_tri_tests;   // the share of box_tests / tri_tests counted inside k_wf_ext launches
 };
 
 __device__ inline unsigned wave_sum(unsigned v) {
@@ -552,8 +553,8 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     if (STATS) {
         const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
         if (lane == 0) {
-            if (bt) atomicAdd(&counters->box_tests, (unsigned long long)bt);
-            if (tt) atomicAdd(&counters->tri_tests, (unsigned long long)tt);
+            if (bt) { atomicAdd(&counters->box_tests, (unsigned long long)bt); atomicAdd(&counters->trav_box_tests, (unsigned long long)bt); }
+            if (tt) { atomicAdd(&counters->tri_tests, (unsigned long long)tt); atomicAdd(&counters->trav_tri_tests, (unsigned long long)tt); }
         }
     }
 }
@@ -693,6 +694,68 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     }
     if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
     wf_shade_counters<STATS>(w, counters, wave, lane, n_seg, n_culled, pc);
+}
+
+// Every remaining round [round0, rounds_end) of a task in one go, by the wave that pulled the task.  Rounds are a
+// dependency chain per path, but the per-round launches also make every path wait for the slowest ray and the slowest
+// chunk of the whole batch, twice per round, plus two launch gaps: once few paths are alive (or the batch is small: one
+// rank's share of a multi-GPU frame) a round costs ~150 us whatever its size.  A task never exchanges paths with another
+// task, so its wave can run traversal -> shading -> traversal ... on its own, at the pace of its own rays, while the other
+// waves of the CU are in other stages of theirs.  Same device functions, same bits.  The stages of one wave communicate
+// through the task's state and record arrays in HBM: a workgroup-scope fence (wait for the stores; all lanes share the
+// CU's L1) orders them.
+#define HRT_TAIL_MAX_MESHES 4
+struct TailMeshes { int n; int prim[HRT_TAIL_MAX_MESHES]; };
+template <bool STATS, int DEPTH>
+__global__ __launch_bounds__(256, 2) void k_wf_tail(DScene sc, hrt_params pr, RenderMap map, WfScene ws, TailMeshes tm, unsigned n_local, int s0, int round0,
+                                                    int rounds_end, WfBuf w, DeviceCounters* counters, int leaf_num) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    __shared__ int s_stack[DEPTH * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
+    __shared__ float s_missq[4][7 * HRT_MISSQ_CAP];
+    stage_tables(sc, s_tables);
+    MissQueue mq;
+    mq.f = s_missq[threadIdx.x >> 6]; mq.slot = (unsigned*)(mq.f + 6 * HRT_MISSQ_CAP); mq.count = 0;
+    unsigned n_seg = 0, n_culled = 0;
+    PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
+    DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+    HRT_FOR_MY_TASKS(task, w, wave, lane) {
+        unsigned live = w.live[task], qn = w.qn[task];     // as the last per-round launches left them
+        for (int r = round0; r < rounds_end && live; ++r) {
+            const int par = r & 1;
+            for (int m = 0; m < tm.n; ++m) {
+                if (m > 0) {
+                    qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, r, par, tm.prim[m - 1] + 1, tm.prim[m], w, task, live, lane, lt, n_culled);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                }
+                if (qn) {
+                    const ExtMesh em = wf_ext_mesh(sc, tm.prim[m]);
+                    bool given = false;
+                    const unsigned first0 = task * w.T, end0 = first0 + qn;
+                    wf_ext_run<STATS>(em, pr, tm.prim[m], par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
+                        if (given) return false;
+                        given = true; first = first0; end = end0;
+                        return true;
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                }
+            }
+            wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, r, w, task, live, lane, lt, mq, pc, n_seg, n_culled, live, qn);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        }
+        if (lane == 0) { w.live[task] = live; w.qn[task] = qn; }
+    }
+    if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
+    wf_shade_counters<STATS>(w, counters, wave, lane, n_seg, n_culled, pc);
+    if (STATS) {
+        const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
+        if (lane == 0) {
+            if (bt) atomicAdd(&counters->box_tests, (unsigned long long)bt);
+            if (tt) atomicAdd(&counters->tri_tests, (unsigned long long)tt);
+        }
+    }
 }
 
 // Per pixel: add the batch's samples IN SAMPLE ORDER (main.cpp:118-124); divide once all samples are in (main.cpp:126).
@@ -931,7 +994,7 @@ size_t wf_max_slots(const hrt_scene* sc) {
 }
 
 // "next task" counters: one block of 256 words per kernel launch of a batch (gen + per round: ext and pre per mesh, shade)
-size_t wf_counter_words(int depth, int n_mesh) { return (size_t)256 * (1 + (size_t)depth * (2 * (size_t)std::max(1, n_mesh) + 1)); }
+size_t wf_counter_words(int depth, int n_mesh) { return (size_t)256 * (2 + (size_t)depth * (2 * (size_t)std::max(1, n_mesh) + 1)); }
 
 hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     WfWorkspace& w = sc->wf;
@@ -993,6 +1056,13 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
     int ext_per_cu_env = 0;                              // experiments: k_wf_ext blocks per CU
     if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu_env = std::min(10, std::max(1, atoi(e)));
+    // from which round on a task's remaining rounds run in one k_wf_tail launch (>= D: never)
+    // Measured (tests/tools/stripe_scaling.py, sweep_env.py): on the full headline frame every switch point loses (49.1 ms
+    // without, 51.5 at round 20, 60.0 with the tail alone), on its 1/8 share round 20 wins 5 % (10.1 -> 9.65 ms).
+    int tail_round = ((size_t)n_local * (size_t)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local)) <= ((size_t)6 << 20)) ? 20 : D;
+    if (const char* e = getenv("HRT_WF_TAIL_ROUND")) tail_round = std::max(1, atoi(e));
+    if (n_mesh > HRT_TAIL_MAX_MESHES) tail_round = D;
+    tail_round = std::min(tail_round, D);
     int leaf_num = 48;                                   // k_wf_ext: start the leaf phase when >= 48/64 of the busy lanes wait at a leaf
     if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
     leaf_num = std::min(64, std::max(1, leaf_num));      // >= 1: with no lane at a leaf the inner loop must go on
@@ -1026,7 +1096,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         next_counters((unsigned)task_blocks * 4u);
         if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         else hipLaunchKernelGGL(k_wf_gen<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
-        for (int r = 0; r < D; ++r) {
+        for (int r = 0; r < tail_round; ++r) {
             const int par = r & 1;
             for (int m = 0; m < n_mesh; ++m) {
                 const int mp = sc->mesh_prims[m];
@@ -1052,6 +1122,19 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
             next_counters((unsigned)task_blocks * 4u);
             if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
             else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
+        }
+        if (tail_round < D) {   // the remaining rounds of every task by the wave that pulls it
+            TailMeshes tm{};
+            tm.n = n_mesh;
+            int need = 0;
+            for (int m = 0; m < n_mesh; ++m) { tm.prim[m] = sc->mesh_prims[m]; need = std::max(need, sc->mesh_depths[m]); }
+            const int variant = need <= 20 ? 20 : (need <= 24 ? 24 : 32);
+            const int tail_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * (variant == 32 ? 2 : 3));   // 46..58 KB of LDS per block
+            next_counters((unsigned)tail_blocks * 4u);
+#define HRT_LAUNCH_TAIL(S, DP) hipLaunchKernelGGL((k_wf_tail<S, DP>), dim3(tail_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, tm, n_local, s0, tail_round, D, w, sc->d_counters, leaf_num)
+            if (stats) { if (variant == 20) HRT_LAUNCH_TAIL(true, 20); else if (variant == 24) HRT_LAUNCH_TAIL(true, 24); else HRT_LAUNCH_TAIL(true, 32); }
+            else { if (variant == 20) HRT_LAUNCH_TAIL(false, 20); else if (variant == 24) HRT_LAUNCH_TAIL(false, 24); else HRT_LAUNCH_TAIL(false, 32); }
+#undef HRT_LAUNCH_TAIL
         }
         const int rblocks = (int)std::min<size_t>((n_local + 255) / 256, (size_t)sc->n_cus * 8);
         hipLaunchKernelGGL(k_wf_reduce, dim3(rblocks), dim3(256), 0, stream, w.rad, n_local, c, s0 == 0 ? 1 : 0, s0 + c >= pr->samples ? 1 : 0, pr->samples, d_out, sc->d_counters, w.wave_rays, w.n_wave_rays);
@@ -1305,6 +1388,7 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
     stats->rays = c.rays; stats->samples = c.samples; stats->box_tests = c.box_tests; stats->tri_tests = c.tri_tests;
     stats->mesh_hits = c.mesh_hits; stats->env_lookups = c.env_lookups;
+    stats->traversal_box_tests = c.trav_box_tests; stats->traversal_tri_tests = c.trav_tri_tests;
     stats->kernel_ms = sc->kernel_ms; stats->launches = sc->launches;
     stats->traversal_ms = sc->traversal_ms; stats->traversal_launches = sc->traversal_launches;
     sc->kernel_ms = 0.0; sc->launches = 0; sc->traversal_ms = 0.0; sc->traversal_launches = 0;

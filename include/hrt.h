@@ -236,6 +236,8 @@ typedef struct hrt_stats {
     double traversal_ms; /* wavefront pipeline with HRT_FLAG_TIMING: time of the BVH traversal kernel (k_wf_ext),
                             summed over its `traversal_launches` launches, from HIP events around each launch */
     uint64_t traversal_launches;
+    uint64_t traversal_box_tests, traversal_tri_tests;   /* the part of box_tests / tri_tests counted inside those k_wf_ext
+                            launches (HRT_FLAG_STATS): rounds that run inside the task-persistent tail kernel are not in it */
 } hrt_stats;
 
 typedef struct hrt_hit {          /* hitRecord (hittable.h:8-25) as seen by rayColour */
