@@ -298,6 +298,8 @@ __device__ inline bool wf_next_task(const WF& w, TaskPuller& p, unsigned lane, u
     ++p.next;
     return true;
 }
+// a per-task count: the same in every lane, but loaded through a vector load -- tell the compiler (loop bounds in SGPRs)
+#define HRT_UNIFORM(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
 #define HRT_FOR_MY_TASKS(task, w, wave, lane)                       \
     TaskPuller puller_ = HRT_TASK_PULLER((wave), (w).n_groups);     \
     for (unsigned task = 0; wf_next_task((w), puller_, (lane), task);)
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned n_culled = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        const unsigned qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, round, par, p0, mesh_prim, w, task, w.live[task], lane, lt, n_culled);
+        const unsigned qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, round, par, p0, mesh_prim, w, task, HRT_UNIFORM(w.live[task]), lane, lt, n_culled);
         if (lane == 0) w.qn[task] = qn;
     }
     if (STATS) {
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_wf_ext(DScene sc, hrt_params pr, 
     wf_ext_run<STATS>(em, pr, mesh_prim, par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
         unsigned t;
         if (!wf_next_task(w, puller, lane, t)) return false;
-        first = t * w.T; end = first + w.qn[t];
+        first = t * w.T; end = first + HRT_UNIFORM(w.qn[t]);
         return true;
     });
     if (STATS) {
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
         unsigned live, qn;
-        wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, round, w, task, w.live[task], lane, lt, mq, pc, n_seg, n_culled, live, qn);
+        wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, round, w, task, HRT_UNIFORM(w.live[task]), lane, lt, mq, pc, n_seg, n_culled, live, qn);
         if (lane == 0) { w.live[task] = live; w.qn[task] = qn; }
     }
     if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void k_wf_tail(DScene sc, hrt_params pr, Re
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        unsigned live = w.live[task], qn = w.qn[task];     // as the last per-round launches left them
+        unsigned live = HRT_UNIFORM(w.live[task]), qn = HRT_UNIFORM(w.qn[task]);     // as the last per-round launches left them
         for (int r = round0; r < rounds_end && live; ++r) {
             const int par = r & 1;
             for (int m = 0; m < tm.n; ++m) {
