@@ -24,7 +24,7 @@ class HrtError(RuntimeError):
 
 # ---------------------------------------------------------------- constants (hrt.h)
 HRT_OK, HRT_ERR_INVALID, HRT_ERR_HIP, HRT_ERR_NO_DEVICE, HRT_ERR_OOM, HRT_ERR_IO, HRT_ERR_PARSE, HRT_ERR_UNSUPPORTED = range(8)
-PRIM_SPHERE, PRIM_XY_RECT, PRIM_XZ_RECT, PRIM_YZ_RECT, PRIM_BOX, PRIM_MESH, PRIM_MEDIUM = range(7)
+PRIM_SPHERE, PRIM_XY_RECT, PRIM_XZ_RECT, PRIM_YZ_RECT, PRIM_BOX, PRIM_MESH, PRIM_MEDIUM, PRIM_TRIANGLE = range(8)
 XF_TRANSLATE, XF_SCALE, XF_ROTATE_QUAT, XF_ROTATE_Y = range(4)
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC, MAT_PBR, MAT_UVTEST = range(7)
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_ENV = range(4)
@@ -41,7 +41,7 @@ class Xform(C.Structure):
 
 class Prim(C.Structure):
     _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("mesh", C.c_int32), ("boundary_kind", C.c_int32),
-                ("p", C.c_float * 8), ("density", C.c_float), ("n_xforms", C.c_int32), ("xf", Xform * MAX_XFORMS)]
+                ("p", C.c_float * 9), ("density", C.c_float), ("n_xforms", C.c_int32), ("xf", Xform * MAX_XFORMS)]
 
 
 class MatVec3(C.Structure):

@@ -240,6 +240,47 @@ __device__ inline void box_rec(const float* p, vec3 o, vec3 d, float t, int side
     rect_rec(axis, rp, o, d, t, rec);
 }
 
+// triangle.cpp:4-40 -- Triangle::hit exactly as written: pV, v0v1 and tV are NORMALISED before use, so u, v and t are not
+// the barycentrics and the distance of Moeller-Trumbore (they only coincide for special rays); back faces are culled
+// (d < 0.0001).  rec.u / rec.v are those values; the normal is the un-normalised face normal, re-faced (hittable.h:19-24).
+template <class P>
+__device__ inline bool triangle_eval(P p, vec3 o, vec3 d, float& t, float& u, float& v) {
+    const vec3 v0(p[0], p[1], p[2]), v1(p[3], p[4], p[5]), v2(p[6], p[7], p[8]);
+    const vec3 v0v1 = v1 - v0;
+    const vec3 v0v2 = v2 - v0;
+    const vec3 pV = normalize(cross(d, v0v2));
+    const float dd = dot(normalize(v0v1), pV);
+    if (dd < 0.0001f) return false;
+    if (fabsf(dd) < 0.0001f) return false;
+    const float invD = 1.0f / dd;
+    const vec3 tV = normalize(o - v0);
+    u = dot(tV, pV) * invD;
+    if (u < 0 || u > 1) return false;
+    const vec3 qV = cross(tV, normalize(v0v1));
+    v = dot(normalize(d), qV) * invD;
+    if (v < 0 || u + v > 1) return false;
+    t = dot(v0v2, qV) * invD;
+    return true;
+}
+template <class P>
+__device__ inline bool triangle_hit(P p, vec3 o, vec3 d, float t_min, float t_max, float& t_out) {
+    float t, u, v;
+    if (!triangle_eval(p, o, d, t, u, v)) return false;
+    if (t < t_min) return false;
+    if (t > t_max) return false;
+    t_out = t;
+    return true;
+}
+template <class P>
+__device__ inline void triangle_rec(P p, vec3 o, vec3 d, DRec& rec) {
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    triangle_eval(p, o, d, t, u, v);
+    rec.t = t; rec.u = u; rec.v = v;
+    rec.p = o + (t * d);
+    const vec3 v0(p[0], p[1], p[2]), v1(p[3], p[4], p[5]), v2(p[6], p[7], p[8]);
+    set_face_normal(rec, d, cross(v1 - v0, v2 - v0));
+}
+
 template <class P>
 __device__ inline bool boundary_hit(int kind, P p, vec3 o, vec3 d, float t_min, float t_max, float& t) {
     int side;
@@ -590,6 +631,8 @@ __device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_m
             hit = box_hit(pr.p, lo, ld, t_min, closest, t, sub);
         } else if (kind == HRT_PRIM_MEDIUM) {
             hit = medium_hit(pr, (uint32_t)i, lo, ld, t_min, closest, ctx, t);
+        } else if (kind == HRT_PRIM_TRIANGLE) {
+            hit = triangle_hit(pr.p, lo, ld, t_min, closest, t);
         } else {
             hit = rect_hit(rect_axis(kind), pr.p, lo, ld, t_min, closest, t);
         }
@@ -613,6 +656,7 @@ __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o,
         if (kind == HRT_PRIM_SPHERE) hit = sphere_hit(pr.p, lo, ld, t_min, closest, t);
         else if (kind == HRT_PRIM_BOX) hit = box_hit(pr.p, lo, ld, t_min, closest, t, sb);
         else if (kind == HRT_PRIM_MEDIUM) hit = medium_hit(pr, (uint32_t)i, lo, ld, t_min, closest, ctx, t);
+        else if (kind == HRT_PRIM_TRIANGLE) hit = triangle_hit(pr.p, lo, ld, t_min, closest, t);
         else hit = rect_hit(rect_axis(kind), pr.p, lo, ld, t_min, closest, t);
         if (hit) { closest = t; prim = i; sub = sb; }
     }
@@ -636,7 +680,8 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     else if (kind == HRT_PRIM_BOX) box_rec(pr.p, lo, ld, wh.t, wh.sub, rec);
     else if (kind == HRT_PRIM_MEDIUM) {  // constantMedium.cpp:30-36
         rec.t = wh.t; rec.p = lo + (wh.t * ld); rec.normal = vec3(1, 0, 0); rec.frontFace = true; rec.u = 0.0f; rec.v = 0.0f;
-    } else rect_rec(rect_axis(kind), pr.p, lo, ld, wh.t, rec);
+    } else if (kind == HRT_PRIM_TRIANGLE) triangle_rec(pr.p, lo, ld, rec);
+    else rect_rec(rect_axis(kind), pr.p, lo, ld, wh.t, rec);
 #pragma unroll
     for (int k = HRT_MAX_XFORMS - 1; k >= 0; --k) {
         if (k < n) xf_unapply(pr.xf[k], rec, dirs[k]);

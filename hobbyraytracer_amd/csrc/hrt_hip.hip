@@ -919,7 +919,7 @@ hrt_status validate(const hrt_flat_scene* f) {
     }
     for (uint32_t i = 0; i < f->n_prims; ++i) {
         const hrt_prim& p = f->prims[i];
-        if (p.kind < HRT_PRIM_SPHERE || p.kind > HRT_PRIM_MEDIUM) return fail(HRT_ERR_INVALID, "prim kind out of range");
+        if (p.kind < HRT_PRIM_SPHERE || p.kind > HRT_PRIM_TRIANGLE) return fail(HRT_ERR_INVALID, "prim kind out of range");
         if (p.material < 0 || (uint32_t)p.material >= f->n_materials) return fail(HRT_ERR_INVALID, "prim material out of range");
         if (p.kind == HRT_PRIM_MESH && (p.mesh < 0 || (uint32_t)p.mesh >= f->n_meshes)) return fail(HRT_ERR_INVALID, "prim mesh out of range");
         if (p.kind == HRT_PRIM_MEDIUM) {

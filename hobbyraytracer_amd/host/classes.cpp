@@ -153,6 +153,11 @@ void HittableList::flatten(FlatBuilder& fb) const {
     }
 }
 void Sphere::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_SPHERE, matPtr); params(p.p); fb.addPrim(p); }
+void Triangle::flatten(FlatBuilder& fb) const {
+    hrt_prim p = basePrim(fb, HRT_PRIM_TRIANGLE, matPtr);
+    p.p[0] = v0.x; p.p[1] = v0.y; p.p[2] = v0.z; p.p[3] = v1.x; p.p[4] = v1.y; p.p[5] = v1.z; p.p[6] = v2.x; p.p[7] = v2.y; p.p[8] = v2.z;
+    fb.addPrim(p);
+}
 void YZRect::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_YZ_RECT, mp); p.p[0] = y0; p.p[1] = y1; p.p[2] = z0; p.p[3] = z1; p.p[4] = k; fb.addPrim(p); }
 void XZRect::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_XZ_RECT, mp); p.p[0] = x0; p.p[1] = x1; p.p[2] = z0; p.p[3] = z1; p.p[4] = k; fb.addPrim(p); }
 void XYRect::flatten(FlatBuilder& fb) const { hrt_prim p = basePrim(fb, HRT_PRIM_XY_RECT, mp); p.p[0] = x0; p.p[1] = x1; p.p[2] = y0; p.p[3] = y1; p.p[4] = k; fb.addPrim(p); }

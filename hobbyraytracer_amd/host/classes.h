@@ -217,6 +217,14 @@ public:
 private:
     vec3 center; float radius; std::shared_ptr<Material> matPtr;
 };
+class Triangle : public Hittable {  // triangle.h:6-19 (the stand-alone triangle; meshes are ITriangle soups)
+public:
+    Triangle() : v0(0.0f), v1(0.0f), v2(0.0f), matPtr(nullptr) {}
+    Triangle(vec3 _v0, vec3 _v1, vec3 _v2, std::shared_ptr<Material> m) : v0(_v0), v1(_v1), v2(_v2), matPtr(m) {}
+    void flatten(FlatBuilder& fb) const override;
+private:
+    vec3 v0, v1, v2; std::shared_ptr<Material> matPtr;
+};
 class YZRect : public Hittable {
 public:
     YZRect(float _y0, float _y1, float _z0, float _z1, float _k, std::shared_ptr<Material> m) : y0(_y0), y1(_y1), z0(_z0), z1(_z1), k(_k), mp(m) {}

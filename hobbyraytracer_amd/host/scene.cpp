@@ -4,7 +4,7 @@
 // Same acceptance set as the reference plus ADDITIVE keys that make the classes
 // the reference cannot reach from YAML loadable:
 //   materials: dielectric{ior, roughness}, isotropic, pbr{metalness, roughness}, uv_test
-//   objects:   box{min,max | center,dimensions}, constant_medium{boundary{sphere|box}, density, colour}
+//   objects:   box{min,max | center,dimensions}, constant_medium{boundary{sphere|box}, density, colour}, triangle{v0,v1,v2}
 //   transform: rotate_y: degrees (innermost)
 // Behavioural differences, all on error paths: an unknown object `type` is
 // reported and fails the load (the reference pushes a nullptr into the world
@@ -201,6 +201,7 @@ int Scene::loadScene(std::string path, std::string assetDirArg) {
                     if (type == "xz_rect") { vec2 X = getVec2("x", object), Z = getVec2("z", object); o = std::make_shared<XZRect>(X.x, X.y, Z.x, Z.y, getFloat("k", object), m); }
                     if (type == "xy_rect") { vec2 X = getVec2("x", object), Y = getVec2("y", object); o = std::make_shared<XYRect>(X.x, X.y, Y.x, Y.y, getFloat("k", object), m); }
                     if (type == "box") o = makeBox(object, m);
+                    if (type == "triangle") o = std::make_shared<Triangle>(getVec3("v0", object), getVec3("v1", object), getVec3("v2", object), m);
                     if (type == "constant_medium") {
                         const Node& b = required("boundary", object);
                         std::string bt = getString("type", b);

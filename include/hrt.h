@@ -57,7 +57,9 @@ enum {
     HRT_PRIM_YZ_RECT = 3,  /* aarect.h:12     p = y0,y1,z0,z1,k                  */
     HRT_PRIM_BOX = 4,      /* box.h           p = min.xyz, max.xyz               */
     HRT_PRIM_MESH = 5,     /* mesh.cpp        mesh = index into meshes[]         */
-    HRT_PRIM_MEDIUM = 6    /* constantMedium.cpp  boundary_kind + p, density     */
+    HRT_PRIM_MEDIUM = 6,   /* constantMedium.cpp  boundary_kind + p, density     */
+    HRT_PRIM_TRIANGLE = 7  /* triangle.cpp:4-40  Triangle (NOT the mesh's ITriangle: nothing in the reference
+                              constructs one)   p = v0.xyz, v1.xyz, v2.xyz */
 };
 
 /* Instance wrappers (translate.cpp, scale.cpp, rotateQuat.cpp, rotateY.cpp).
@@ -80,7 +82,7 @@ typedef struct hrt_prim {
     int32_t material;        /* index into materials[] (MEDIUM: the Isotropic phase function) */
     int32_t mesh;            /* HRT_PRIM_MESH only */
     int32_t boundary_kind;   /* HRT_PRIM_MEDIUM only: HRT_PRIM_SPHERE or HRT_PRIM_BOX */
-    float p[8];
+    float p[9];
     float density;           /* HRT_PRIM_MEDIUM only */
     int32_t n_xforms;
     hrt_xform xf[HRT_MAX_XFORMS];

@@ -320,6 +320,40 @@ struct Sphere : Hittable {
     bool boundingBox(AABB& out) override { out = AABB(center - vec3(radius), center + vec3(radius)); return true; }
 };
 
+// ---------------------------------------------------------------- triangle.cpp:4-55 (Triangle; meshes use ITriangle below)
+struct Triangle : Hittable {
+    vec3 v0, v1, v2; const Material* matPtr;
+    bool hit(const ray& r, float t_min, float t_max, hitRecord& rec) const override {  // triangle.cpp:4-40
+        vec3 v0v1 = v1 - v0;
+        vec3 v0v2 = v2 - v0;
+        vec3 pV = normalize(cross(r.dir, v0v2));
+        float d = dot(normalize(v0v1), pV);
+        if (d < 0.0001f) return false;
+        if (fabsf(d) < 0.0001f) return false;
+        float invD = 1.0f / d;
+        vec3 tV = normalize(r.o - v0);
+        rec.u = dot(tV, pV) * invD;
+        if (rec.u < 0 || rec.u > 1) return false;
+        vec3 qV = cross(tV, normalize(v0v1));
+        rec.v = dot(normalize(r.dir), qV) * invD;
+        if (rec.v < 0 || rec.u + rec.v > 1) return false;
+        rec.t = dot(v0v2, qV) * invD;
+        if (rec.t < t_min) return false;
+        if (rec.t > t_max) return false;
+        rec.p = r.at(rec.t);
+        rec.matPtr = matPtr;
+        rec.setFaceNormal(r, cross(v0v1, v0v2));
+        rec.tri = -1;
+        return true;
+    }
+    bool boundingBox(AABB& out) override {  // triangle.cpp:42-55
+        vec3 mn(gmin(gmin(v0.x, v1.x), v2.x), gmin(gmin(v0.y, v1.y), v2.y), gmin(gmin(v0.z, v1.z), v2.z));
+        vec3 mx(gmax(gmax(v0.x, v1.x), v2.x), gmax(gmax(v0.y, v1.y), v2.y), gmax(gmax(v0.z, v1.z), v2.z));
+        out = AABB(mn - vec3(0.0001f), mx + vec3(0.0001f));
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------- aarect.h
 struct YZRect : Hittable {  // aarect.h:12-39
     float y0, y1, z0, z1, k; const Material* mp;
@@ -662,6 +696,7 @@ static Hittable* build_leaf(World& w, const hrt_flat_scene* fs, int kind, const 
         case HRT_PRIM_XZ_RECT: h = new XZRect(p[0], p[1], p[2], p[3], p[4], m); break;
         case HRT_PRIM_YZ_RECT: h = new YZRect(p[0], p[1], p[2], p[3], p[4], m); break;
         case HRT_PRIM_BOX: h = new Box(vec3(p[0], p[1], p[2]), vec3(p[3], p[4], p[5]), m); break;
+        case HRT_PRIM_TRIANGLE: { auto* t = new Triangle; t->v0 = vec3(p[0], p[1], p[2]); t->v1 = vec3(p[3], p[4], p[5]); t->v2 = vec3(p[6], p[7], p[8]); t->matPtr = m; h = t; break; }
         case HRT_PRIM_MESH: {
             const hrt_mesh& mm = fs->meshes[mesh];
             h = new Mesh(fs->tri_pos + 9ull * mm.tri_first, fs->tri_nrm + 9ull * mm.tri_first, fs->tri_uv + 6ull * mm.tri_first,

@@ -12,6 +12,7 @@ SCENES = {  # name -> (W, H, spp)
     "bust_scene.yaml": (40, 40, 4),
     "material_zoo.yaml": (56, 56, 6),
     "three_meshes.yaml": (60, 40, 4),      # several meshes interleaved with analytic prims in the world list
+    "triangles.yaml": (60, 40, 4),         # the stand-alone Triangle class (triangle.cpp:4-40)
 }
 
 

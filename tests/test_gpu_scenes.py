@@ -11,6 +11,7 @@ SCENES = {  # name -> (W, H, spp)
     "cornell_box.yaml": (96, 96, 16),       # C2: rects, boxes (rotate_y / rotate wrappers), rough dielectric + metal spheres
     "bust_scene.yaml": (80, 80, 8),         # C5: dielectric mesh in one Translate, ConstantMedium (RNG inside hit), checker floor
     "material_zoo.yaml": (96, 96, 12),      # image / checker textures, pbr, uv_test, isotropic in a box, 3-wrapper mesh
+    "triangles.yaml": (96, 64, 8),          # the stand-alone Triangle class (triangle.cpp:4-40), also under wrappers and as a light
     "three_meshes.yaml": (96, 64, 8),       # three meshes (3 wrappers / 1 / none) interleaved with spheres and rects: k_wf_pre, one traversal per mesh
 }
 
@@ -41,11 +42,11 @@ def test_image_parity(built, assets, scenes_dir, scene, quirks, path):
 
 def test_closest_hit_all_primitive_kinds(built, assets, scenes_dir):
     """hitRecord parity (t, p, normal, u, v, frontFace) for spheres, rects, boxes under RotateY / RotateQuat,
-    a medium (RNG inside hit) and a 3-wrapper mesh."""
+    a medium (RNG inside hit), a 3-wrapper mesh, stand-alone Triangles, several meshes in one world."""
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
     r = np.random.default_rng(17)
-    for scene in ("cornell_box.yaml", "material_zoo.yaml", "bust_scene.yaml"):
+    for scene in ("cornell_box.yaml", "material_zoo.yaml", "bust_scene.yaml", "triangles.yaml", "three_meshes.yaml"):
         hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
         dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
         o = r.uniform([-3, 0.05, -3], [3, 4.5, 7], (150000, 3)).astype(np.float32)
@@ -198,7 +199,7 @@ def test_world_larger_than_the_lds_tables(built, assets, tmp_path):
     (tmp_path / "many.yaml").write_text(yaml)
     shutil.copy(f"{assets}/teapot.obj", tmp_path / "teapot.obj")
     hs = api.HostScene(str(tmp_path / "many.yaml"), str(tmp_path))
-    assert hs.flat.n_prims == 152 and hs.flat.n_prims * 136 > 12288
+    assert hs.flat.n_prims == 152 and hs.flat.n_prims * 140 > 12288
     dev = api.DeviceScene(hs.flat_ptr, 0)
     W, H, spp = 96, 64, 6
     cam = hs.camera(W, H)

@@ -180,6 +180,11 @@ def test_additive_keys(built, assets, scenes_dir):
     med = [hs2.flat.prims[i] for i in range(hs2.flat.n_prims) if hs2.flat.prims[i].kind == api.PRIM_MEDIUM][0]
     assert med.boundary_kind == api.PRIM_SPHERE and abs(med.density - 0.12) < 1e-7
     assert hs2.flat.materials[med.material].kind == api.MAT_ISOTROPIC
+    hs3 = api.HostScene(f"{scenes_dir}/triangles.yaml", assets)          # the stand-alone Triangle (triangle.h:6-19)
+    tris = [hs3.flat.prims[i] for i in range(hs3.flat.n_prims) if hs3.flat.prims[i].kind == api.PRIM_TRIANGLE]
+    assert len(tris) == 4 and hs3.flat.n_meshes == 0
+    np.testing.assert_allclose(list(tris[0].p), [-2.5, 0, 0, -0.8, 0, 0.5, -1.6, 1.8, 0.2], rtol=1e-6)
+    assert [tris[2].xf[k].kind for k in range(tris[2].n_xforms)] == [api.XF_TRANSLATE, api.XF_SCALE, api.XF_ROTATE_QUAT]
 
 
 def test_obj_import_matches_assimp_flags(built, tmp_path):
