@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--megakernel", action="store_true", help="time the persistent-lanes megakernel instead of the wavefront pipeline")
+    ap.add_argument("--film-out", default="", help="rank 0 writes the gathered fp32 film of the last step to this .npy file (tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; 'gloo' only to rehearse N > 1 "
                     "with all ranks sharing one GPU, where RCCL refuses duplicate devices)")
     args = ap.parse_args()
@@ -161,6 +162,9 @@ def main():
     sync()
     t1 = time.perf_counter()
     st = dev.stats()
+
+    if rank == 0 and args.film_out:
+        np.save(args.film_out, film_lin.cpu().numpy())
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     counts = torch.tensor([float(st.rays), float(st.samples), float(alg_bytes_launch)], dtype=torch.float64, device="cuda")

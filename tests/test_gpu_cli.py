@@ -70,3 +70,32 @@ def test_cli_progressive_checkpoint_resume(built, assets, scenes_dir, tmp_path):
     p = subprocess.run([api.CLI_PATH, "s.yaml", "--size", "80x45", "--spp", "12", "--seed", "4", "--checkpoint", "ck.bin", "--resume"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert p.returncode != 1 and "different render" in p.stderr
+
+
+def test_bench_under_torchrun_two_ranks_on_one_gpu(built, assets, scenes_dir, tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run, one process per rank,
+    rendezvous on 127.0.0.1), here with 2 ranks sharing the one GPU of the box and gloo as the collective backend (RCCL
+    refuses two ranks on one device): interleaved row blocks + all_gather + row permutation give the single-process film
+    bit for bit, and the JSON line carries the contract's fields."""
+    import json
+    import sys
+    from hobbyraytracer_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--width", "96", "--height", "72", "--spp", "4", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--film-out", str(tmp_path / "one.npy")],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", *common, "--backend", "gloo",
+                          "--film-out", str(tmp_path / "two.npy")], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert a.shape == (72, 96, 3) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE JSON line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["unit"] == "Mrays/s" and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["samples_per_step"] == 96 * 72 * 4 and "roofline" in j and "cpu_baseline" not in j   # cpu_baseline: N = 1 only
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert j1["config"]["rays_per_step"] == j["config"]["rays_per_step"]      # both ranks' segments add up to the single-GPU count
