@@ -1081,6 +1081,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         const size_t t_large = round64(n_slots / ((size_t)sc->n_cus * 64));
         const size_t t_small = std::min<size_t>(1280, std::max<size_t>(256, round64(n_slots / ((size_t)sc->n_cus * 16))));
         size_t T = std::min<size_t>(4096, std::max(t_large, t_small));
+        if (const char* e = getenv("HRT_WF_TASK_SIZE")) T = std::min<size_t>(4096, std::max<size_t>(64, round64((size_t)atoi(e))));   // experiments
         w.T = (unsigned)T;
         w.n_tasks = (unsigned)((n_slots + T - 1) / T);
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
