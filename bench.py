@@ -215,7 +215,7 @@ def main():
                     pass
         pipeline_gbps = alg_bytes_launch / (frame_ms * 1e-3) / 1e9
         result = {
-            "metric": "Mrays/sec (path segments/s), teapot_scene.yaml 640x640 100spp",
+            "metric": f"Mrays/sec (path segments/s), {args.scene} {W}x{H} {spp}spp",
             "value": round(mrays, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -226,7 +226,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (procedural teapot.obj ~6.2k tris + procedural 4096x2048 old_hall_4k.hdr stand-ins; seed 0)",
+            "data": "synthetic (procedural teapot.obj ~6.2k tris" + (" / marble_bust_01.obj ~100k tris" if "bust" in args.scene else "") +
+                    " + procedural 4096x2048 old_hall_4k.hdr stand-ins; seed 0)",
             "config": {"workload": f"{args.scene} {W}x{H} {spp}spp, quirks={args.quirks}, max_depth=50",
                        "render_path": "megakernel k_pathtrace" if args.megakernel else "wavefront pipeline k_wf_gen/pre/ext/shade/reduce",
                        "parallelism": f"image row blocks of {R} rows interleaved over {world} GPU(s); RCCL all_gather of fp32 film tiles" if world > 1 else "single GPU",
