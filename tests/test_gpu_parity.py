@@ -196,7 +196,7 @@ def test_wavefront_sample_chunking_and_paths_agree(teapot, monkeypatch):
     monkeypatch.delenv("HRT_WF_MAX_SLOTS"); monkeypatch.delenv("HRT_WF_DYNAMIC_TASKS")
     assert np.array_equal(one.view(np.uint32), pulled.view(np.uint32))
     assert np.array_equal(one.view(np.uint32), pulled_chunked.view(np.uint32))
-    # nor can the round from which a task's remaining rounds run inside one k_wf_tail launch (small tiles: 20 by default)
+    # nor can the round from which a task's remaining rounds run inside one k_wf_tail launch (tiny batches: 1, small: 20, else never)
     tails = []
     for tr in ("1", "2", "7", "50"):
         monkeypatch.setenv("HRT_WF_TAIL_ROUND", tr)
@@ -206,7 +206,8 @@ def test_wavefront_sample_chunking_and_paths_agree(teapot, monkeypatch):
     monkeypatch.delenv("HRT_WF_TAIL_ROUND")
     # hrt_stats.traversal_*: what the k_wf_ext LAUNCHES tested (the rest: root-filter tests of gen/pre/shade and the tail's rounds)
     assert tails[0].traversal_box_tests == 0 and tails[0].traversal_tri_tests == 0
-    assert 0 < tails[1].traversal_box_tests < tails[2].traversal_box_tests < s1.traversal_box_tests < tails[3].traversal_box_tests < s1.box_tests
+    assert 0 < tails[1].traversal_box_tests < tails[2].traversal_box_tests < tails[3].traversal_box_tests < s1.box_tests
+    assert s1.traversal_box_tests == 0          # this tile is a tiny batch: by default its tasks run all rounds inside k_wf_tail
     assert tails[3].traversal_tri_tests == s1.tri_tests
     for a in (s2, s3, s4, s5, *tails):
         assert (a.rays, a.samples, a.box_tests, a.tri_tests, a.mesh_hits, a.env_lookups) == \
