@@ -16,12 +16,15 @@ SCENES = {  # name -> (W, H, spp)
 }
 
 
-@pytest.mark.parametrize("path", ["wavefront", "megakernel"])
+# the three ways a film gets rendered: per-round kernels (k_wf_gen / pre / ext / shade, what large batches use), every round of
+# a task inside k_wf_tail (what these small films use by default), the megakernel
+@pytest.mark.parametrize("path", ["wavefront-rounds", "wavefront-tail", "megakernel"])
 @pytest.mark.parametrize("quirks", ["reference", "fixed"])
 @pytest.mark.parametrize("scene", sorted(SCENES))
-def test_image_parity(built, assets, scenes_dir, scene, quirks, path):
+def test_image_parity(built, assets, scenes_dir, scene, quirks, path, monkeypatch):
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
+    monkeypatch.setenv("HRT_WF_TAIL_ROUND", "1000" if path == "wavefront-rounds" else "1")
     W, H, spp = SCENES[scene]
     hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
     q = api.QUIRKS_REFERENCE if quirks == "reference" else api.QUIRKS_FIXED
