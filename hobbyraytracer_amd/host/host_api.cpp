@@ -145,4 +145,21 @@ hrt_status hrt_host_write_hdr(const char* path, const float* rgb, int32_t w, int
     return writeHDR(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
 }
 
+hrt_status hrt_host_write_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
+    return writePFM(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+}
+hrt_status hrt_host_read_pfm(const char* path, int32_t* w, int32_t* h, float* out, int64_t cap) {
+    if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
+    std::vector<float> rgb;
+    int iw = 0, ih = 0;
+    std::string err;
+    if (!readPFM(path, rgb, iw, ih, err)) return hfail(HRT_ERR_IO, err);
+    *w = iw; *h = ih;
+    if (!out) return HRT_OK;
+    if (cap < (int64_t)rgb.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
+    std::memcpy(out, rgb.data(), rgb.size() * sizeof(float));
+    return HRT_OK;
+}
+
 }  // extern "C"

@@ -108,6 +108,33 @@ bool readHDR(const std::string& path, std::vector<float>& rgb, int& w, int& h, s
     return true;
 }
 
+bool writePFM(const std::string& path, const float* rgb, int w, int h) {
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h);                       // negative scale = little-endian
+    bool ok = true;
+    for (int y = h - 1; y >= 0 && ok; --y) ok = std::fwrite(rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f) == (size_t)w * 3;
+    return (std::fclose(f) == 0) && ok;
+}
+bool readPFM(const std::string& path, std::vector<float>& rgb, int& w, int& h, std::string& err) {
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    char magic[3] = {0, 0, 0};
+    float scale = 0.0f;
+    if (std::fscanf(f, "%2s %d %d %f", magic, &w, &h, &scale) != 4 || std::strcmp(magic, "PF") != 0 || w < 1 || h < 1 || !(scale < 0.0f)) {
+        std::fclose(f);
+        err = path + " is not a little-endian colour PFM";
+        return false;
+    }
+    std::fgetc(f);                                                      // the single whitespace after the scale
+    rgb.resize((size_t)w * h * 3);
+    bool ok = true;
+    for (int y = h - 1; y >= 0 && ok; --y) ok = std::fread(&rgb[(size_t)y * w * 3], sizeof(float), (size_t)w * 3, f) == (size_t)w * 3;
+    std::fclose(f);
+    if (!ok) err = path + " is truncated";
+    return ok;
+}
+
 bool writeHDR(const std::string& path, const float* rgb, int w, int h) {
     std::FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return false;

@@ -9,6 +9,7 @@
 //     --progressive N (take the samples in passes of N and rewrite the output image after every pass)
 //     --checkpoint FILE (store the accumulation buffer after every pass)   --resume (continue from that file)
 //     --max-passes K (stop after K passes; with --checkpoint the render can be resumed later)
+//     --dump-linear FILE.pfm (the fp32 linear film, bit for bit, next to the tonemapped image)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 
 #include "assets.h"
 #include "classes.h"
+#include "image_io.h"
 #include "render.h"
 
 using namespace hrthost;
@@ -36,7 +38,7 @@ static void printElapsed(const char* what, std::chrono::high_resolution_clock::t
 int main(int argc, char** argv) {
     auto start = std::chrono::high_resolution_clock::now();
     std::string file = "teapot_scene.yaml";  // main.cpp:146
-    std::string assets, out, makeAssets;
+    std::string assets, out, makeAssets, dumpLinear;
     RenderOptions opt;
     int spp = -1, sw = -1, sh = -1;
     bool haveFile = false;
@@ -59,6 +61,7 @@ int main(int argc, char** argv) {
         else if (a == "--checkpoint") opt.checkpoint = next("--checkpoint");
         else if (a == "--resume") opt.resume = true;
         else if (a == "--max-passes") opt.max_passes = std::atoi(next("--max-passes"));
+        else if (a == "--dump-linear") dumpLinear = next("--dump-linear");
         else if (!haveFile) { file = a; haveFile = true; }
     }
     if (!makeAssets.empty()) {
@@ -92,6 +95,10 @@ int main(int argc, char** argv) {
     if (st != HRT_OK) return -1;
 
     int r = film->outputFilm();
+    if (!dumpLinear.empty() && !writePFM(dumpLinear, film->linear().data(), film->getFilm().width, film->getFilm().height)) {
+        std::cerr << "cannot write " << dumpLinear << std::endl;
+        return -1;
+    }
 
     if (opt.stats || std::getenv("HRT_STATS")) {
         const double bytes = 32.0 * stats.box_tests + 36.0 * stats.tri_tests + 60.0 * stats.mesh_hits + 12.0 * stats.env_lookups +

@@ -52,6 +52,10 @@ hrt_status hrt_host_write_image(const char* path, const uint8_t* rgb, int32_t wi
 hrt_status hrt_host_read_hdr(const char* path, int32_t* width, int32_t* height, float* out, int64_t out_cap_floats);
 hrt_status hrt_host_read_png(const char* path, int32_t* width, int32_t* height, uint8_t* out, int64_t out_cap_bytes);
 hrt_status hrt_host_write_hdr(const char* path, const float* rgb, int32_t width, int32_t height);
+/* The fp32 linear film bit for bit (Portable Float Map, little-endian, colour): the dump to diff two renders exactly
+ * (Radiance RGBE keeps 8 mantissa bits).  Rows are handed over top first, like everywhere else. */
+hrt_status hrt_host_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
+hrt_status hrt_host_read_pfm(const char* path, int32_t* width, int32_t* height, float* out, int64_t out_cap_floats);
 
 const char* hrt_host_last_error(void);
 

@@ -32,6 +32,10 @@ def test_cli_renders_the_default_scene_and_matches_the_oracle(built, assets, sce
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert p.returncode == 1 and "File type not supported, generating bitmap!" in p.stdout
     assert open(tmp_path / "x.foo", "rb").read(2) == b"BM"
+    # --dump-linear: the fp32 film, bit for bit the oracle's
+    p = subprocess.run([api.CLI_PATH, "--size", "64x64", "--spp", "6", "--dump-linear", "film.pfm"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1
+    assert np.array_equal(api.read_pfm(str(tmp_path / "film.pfm")).view(np.uint32), ref.view(np.uint32))
 
 
 def test_cli_make_assets(built, tmp_path):

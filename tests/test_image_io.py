@@ -111,3 +111,23 @@ def test_bmp_and_tga_writers(built, tmp_path):
     # unknown suffix -> bitmap (film.cpp:73-78)
     api.write_image(str(tmp_path / "a.xyz"), img)
     assert open(tmp_path / "a.xyz", "rb").read()[:2] == b"BM"
+
+
+def test_pfm_film_dump_is_bit_exact(built, tmp_path):
+    """hrt_host_write_pfm / read_pfm: the fp32 film survives bit for bit (NaN payloads, denormals, -0, inf included), rows
+    stored bottom first with a little-endian scale line as the format asks."""
+    from hobbyraytracer_amd import api
+    r = np.random.default_rng(4)
+    a = r.standard_normal((7, 5, 3)).astype(np.float32) * np.float32(1e3)
+    a[0, 0] = [np.nan, np.inf, -np.inf]
+    a[1, 1] = [np.float32(-0.0), np.float32(1e-45), np.float32(3.4e38)]
+    a.view(np.uint32)[2, 2, 0] = 0x7fc12345                      # a NaN with a payload
+    api.write_pfm(str(tmp_path / "f.pfm"), a)
+    raw = open(tmp_path / "f.pfm", "rb").read()
+    assert raw.startswith(b"PF\n5 7\n-1.0\n") and len(raw) == len(b"PF\n5 7\n-1.0\n") + a.nbytes
+    assert np.array_equal(np.frombuffer(raw[-a.nbytes:], "<f4").reshape(7, 5, 3)[::-1].view(np.uint32), a.view(np.uint32))
+    b = api.read_pfm(str(tmp_path / "f.pfm"))
+    assert b.shape == a.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    (tmp_path / "bad.pfm").write_bytes(b"Pf\n5 7\n-1.0\n" + bytes(10))
+    with pytest.raises(api.HrtError):
+        api.read_pfm(str(tmp_path / "bad.pfm"))
