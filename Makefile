@@ -13,7 +13,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Wno-u
 
 PKG      := hobbyraytracer_amd
 HOST_SRC := $(PKG)/host/classes.cpp $(PKG)/host/bvh_build.cpp $(PKG)/host/scene.cpp $(PKG)/host/yaml_lite.cpp \
-            $(PKG)/host/image_io.cpp $(PKG)/host/assets.cpp $(PKG)/host/host_api.cpp
+            $(PKG)/host/image_io.cpp $(PKG)/host/jpeg_lite.cpp $(PKG)/host/assets.cpp $(PKG)/host/host_api.cpp
 HOST_HDR := $(wildcard $(PKG)/host/*.h) $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
 
 all: $(PKG)/lib/libhrt_hip.so $(PKG)/lib/libhrt_host.so $(PKG)/bin/hobbyraytracer oracle/liboracle.so

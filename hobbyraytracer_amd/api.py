@@ -126,7 +126,7 @@ HIP_SYMBOLS = ["hrt_device_count", "hrt_scene_create", "hrt_scene_destroy", "hrt
                "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version"]
 HOST_SYMBOLS = ["hrt_host_load_yaml", "hrt_host_free", "hrt_host_flat", "hrt_host_film", "hrt_host_camera", "hrt_host_bvh_depth",
                 "hrt_default_params", "hrt_asset_write_teapot_obj", "hrt_asset_write_bust_obj", "hrt_asset_write_hall_hdr",
-                "hrt_host_write_image", "hrt_host_read_hdr", "hrt_host_read_png", "hrt_host_write_hdr", "hrt_host_write_pfm", "hrt_host_read_pfm", "hrt_host_last_error"]
+                "hrt_host_write_image", "hrt_host_read_hdr", "hrt_host_read_png", "hrt_host_read_jpeg", "hrt_host_write_hdr", "hrt_host_write_pfm", "hrt_host_read_pfm", "hrt_host_last_error"]
 
 
 def _load(path):
@@ -187,6 +187,7 @@ _host.hrt_asset_write_hall_hdr.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
 _host.hrt_host_write_image.argtypes = [C.c_char_p, _u8p, C.c_int32, C.c_int32]
 _host.hrt_host_read_hdr.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp, C.c_int64]
 _host.hrt_host_read_png.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p, C.c_int64]
+_host.hrt_host_read_jpeg.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p, C.c_int64]
 _host.hrt_host_write_hdr.argtypes = [C.c_char_p, _fp, C.c_int32, C.c_int32]
 _host.hrt_host_write_pfm.argtypes = [C.c_char_p, _fp, C.c_int32, C.c_int32]
 _host.hrt_host_read_pfm.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _fp, C.c_int64]
@@ -302,6 +303,14 @@ def write_hdr(path, rgb):
     a = _f32(rgb)
     h, w, _ = a.shape
     _check_host(_host.hrt_host_write_hdr(os.fsencode(path), _ptr(a), w, h))
+
+
+def read_jpeg(path):
+    w, h = C.c_int32(), C.c_int32()
+    _check_host(_host.hrt_host_read_jpeg(os.fsencode(path), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    _check_host(_host.hrt_host_read_jpeg(os.fsencode(path), C.byref(w), C.byref(h), _ptr(out, _u8p), out.size))
+    return out
 
 
 def write_pfm(path, rgb):

@@ -7,6 +7,7 @@
 #include "assets.h"
 #include "classes.h"
 #include "image_io.h"
+#include "jpeg_lite.h"
 
 using namespace hrthost;
 
@@ -145,6 +146,18 @@ hrt_status hrt_host_write_hdr(const char* path, const float* rgb, int32_t w, int
     return writeHDR(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
 }
 
+hrt_status hrt_host_read_jpeg(const char* path, int32_t* w, int32_t* h, uint8_t* out, int64_t cap) {
+    if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
+    std::vector<uint8_t> d;
+    int ww = 0, hh = 0;
+    std::string err;
+    if (!readJPEG(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
+    *w = ww; *h = hh;
+    if (!out) return HRT_OK;
+    if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
+    std::memcpy(out, d.data(), d.size());
+    return HRT_OK;
+}
 hrt_status hrt_host_write_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {
     if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
     return writePFM(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);

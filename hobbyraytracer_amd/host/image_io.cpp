@@ -8,6 +8,7 @@
 // linearised with gamma 2.2 (stbi_loadf's ldr_to_hdr); JPEG is not supported
 // (reported as a load failure, which the reference renders as cyan).
 #include "image_io.h"
+#include "jpeg_lite.h"
 
 #include <zlib.h>
 
@@ -310,6 +311,7 @@ bool loadImageRGB8(const std::string& path, std::vector<uint8_t>& rgb, int& w, i
     std::string lower = path;
     for (char& c : lower) c = (char)std::tolower((unsigned char)c);
     if (ends_with(lower, ".png")) return readPNG(path, rgb, w, h, err);
+    if (ends_with(lower, ".jpg") || ends_with(lower, ".jpeg")) return readJPEG(path, rgb, w, h, err);
     if (ends_with(lower, ".hdr")) {  // stbi_load on an HDR file: hdr_to_ldr (gamma 1/2.2, scale 1)
         std::vector<float> f;
         if (!readHDR(path, f, w, h, err)) return false;
@@ -321,22 +323,23 @@ bool loadImageRGB8(const std::string& path, std::vector<uint8_t>& rgb, int& w, i
         }
         return true;
     }
-    err = "unsupported image format (only .png and .hdr are decoded): " + path;
+    err = "unsupported image format (.png, .jpg and .hdr are decoded): " + path;
     return false;
 }
 bool loadImageF32(const std::string& path, std::vector<float>& data, int& w, int& h, int& channels, std::string& err) {
     std::string lower = path;
     for (char& c : lower) c = (char)std::tolower((unsigned char)c);
     if (ends_with(lower, ".hdr")) { channels = 3; return readHDR(path, data, w, h, err); }
-    if (ends_with(lower, ".png")) {  // stbi_loadf on an LDR file: ldr_to_hdr, pow(v/255, 2.2)
+    const bool jpg = ends_with(lower, ".jpg") || ends_with(lower, ".jpeg");
+    if (ends_with(lower, ".png") || jpg) {  // stbi_loadf on an LDR file: ldr_to_hdr, pow(v/255, 2.2)
         std::vector<uint8_t> rgb;
-        if (!readPNG(path, rgb, w, h, err)) return false;
+        if (!(jpg ? readJPEG(path, rgb, w, h, err) : readPNG(path, rgb, w, h, err))) return false;
         channels = 3;
         data.resize(rgb.size());
         for (size_t i = 0; i < rgb.size(); ++i) data[i] = std::pow(rgb[i] / 255.0f, 2.2f);
         return true;
     }
-    err = "unsupported image format (only .hdr and .png are decoded): " + path;
+    err = "unsupported image format (.hdr, .png and .jpg are decoded): " + path;
     return false;
 }
 

@@ -51,6 +51,8 @@ hrt_status hrt_host_write_image(const char* path, const uint8_t* rgb, int32_t wi
  * with out == NULL to query the size), PNG -> 3 x u8. */
 hrt_status hrt_host_read_hdr(const char* path, int32_t* width, int32_t* height, float* out, int64_t out_cap_floats);
 hrt_status hrt_host_read_png(const char* path, int32_t* width, int32_t* height, uint8_t* out, int64_t out_cap_bytes);
+/* Baseline JPEG -> 3 x u8 (what ImageTexture gets from stbi_load(path, ..., 3), texture.cpp:34-36). */
+hrt_status hrt_host_read_jpeg(const char* path, int32_t* width, int32_t* height, uint8_t* out, int64_t out_cap_bytes);
 hrt_status hrt_host_write_hdr(const char* path, const float* rgb, int32_t width, int32_t height);
 /* The fp32 linear film bit for bit (Portable Float Map, little-endian, colour): the dump to diff two renders exactly
  * (Radiance RGBE keeps 8 mantissa bits).  Rows are handed over top first, like everywhere else. */

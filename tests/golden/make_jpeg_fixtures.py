@@ -1,0 +1,55 @@
+"""Generates tests/golden/jpeg/*.jpg and jpeg_expected.npz: small JPEG files of every flavour the product's decoder
+(hobbyraytracer_amd/host/jpeg_lite.cpp) accepts -- written by the reference's own stb_image_write (quality 95 -> 4:4:4,
+quality 60 -> 4:2:0) and by Pillow/libjpeg (4:2:2, 4:4:0, grey, restart intervals, odd sizes, a progressive file that must be
+refused) -- together with the pixels the REFERENCE's decoder, stbi_load(path, &w, &h, &n, 3) of the vendored stb_image.h
+(oracle/_ref/libstbref.so), returns for them.  Fixtures are data.  Run in the build container (needs /root/reference and Pillow):
+    python tests/golden/make_jpeg_fixtures.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+if __name__ == "__main__":
+    out = os.path.join(HERE, "jpeg")
+    os.makedirs(out, exist_ok=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libstbref.so"))
+    lib.stbi_load.restype = C.POINTER(C.c_ubyte)
+    lib.stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    lib.stbi_write_jpg.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    r = np.random.default_rng(77)
+
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 5.0 + y / 9.0), 127 + 120 * np.cos(x / 7.0) * np.sin(y / 4.0), (x * 255 // max(1, w - 1) + y * 3) % 256], -1)
+        img += r.normal(0, 12, img.shape)
+        img[h // 3:h // 2, w // 4:w // 2] = [250, 10, 30]            # a hard-edged saturated patch (chroma filters, clamping)
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+    files = {}
+    a = picture(37, 53)
+    for name, q in (("stb_q95_444.jpg", 95), ("stb_q60_420.jpg", 60), ("stb_q5_420.jpg", 5)):
+        assert lib.stbi_write_jpg(os.path.join(out, name).encode(), 53, 37, 3, a.ctypes.data, q) == 1
+        files[name] = None
+    b = picture(48, 64)
+    pil = Image.fromarray(b)
+    pil.save(os.path.join(out, "pil_444.jpg"), quality=90, subsampling=0); files["pil_444.jpg"] = None
+    pil.save(os.path.join(out, "pil_422.jpg"), quality=85, subsampling=1); files["pil_422.jpg"] = None
+    pil.save(os.path.join(out, "pil_420_restart.jpg"), quality=80, subsampling=2, restart_marker_blocks=3); files["pil_420_restart.jpg"] = None
+    Image.fromarray(picture(31, 17)).save(os.path.join(out, "pil_420_odd.jpg"), quality=75, subsampling=2); files["pil_420_odd.jpg"] = None
+    Image.fromarray(picture(9, 1)).save(os.path.join(out, "pil_420_1wide.jpg"), quality=75, subsampling=2); files["pil_420_1wide.jpg"] = None
+    Image.fromarray(picture(33, 41)[:, :, 0]).save(os.path.join(out, "pil_grey.jpg"), quality=70); files["pil_grey.jpg"] = None
+    pil.save(os.path.join(out, "pil_optimised_tables.jpg"), quality=60, subsampling=2, optimize=True); files["pil_optimised_tables.jpg"] = None
+    pil.save(os.path.join(out, "pil_progressive.jpg"), quality=80, progressive=True)    # must be refused by the product
+    exp = {}
+    for name in files:
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        p = lib.stbi_load(os.path.join(out, name).encode(), C.byref(w), C.byref(h), C.byref(n), 3)
+        assert p, name
+        exp[name] = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    np.savez_compressed(os.path.join(HERE, "jpeg_expected.npz"), **exp)
+    print("wrote", len(exp), "fixtures", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)), "bytes")

@@ -131,3 +131,73 @@ def test_pfm_film_dump_is_bit_exact(built, tmp_path):
     (tmp_path / "bad.pfm").write_bytes(b"Pf\n5 7\n-1.0\n" + bytes(10))
     with pytest.raises(api.HrtError):
         api.read_pfm(str(tmp_path / "bad.pfm"))
+
+
+def test_jpeg_decoder_matches_the_references_stb(built):
+    """hobbyraytracer_amd/host/jpeg_lite.cpp against stbi_load(path, ..., 3) of the stb_image.h the reference vendors
+    (texture.cpp:34-36), on files written by the reference's stb_image_write and by libjpeg: 4:4:4, 4:2:2, 4:2:0 (odd sizes,
+    one pixel wide, restart intervals, optimised Huffman tables, quality 5 with clamping everywhere), grey.  Expected pixels
+    were produced by the reference's decoder itself (tests/golden/make_jpeg_fixtures.py).  Bit-exact; progressive is refused."""
+    from hobbyraytracer_amd import api
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = np.load(os.path.join(here, "jpeg_expected.npz"))
+    assert len(exp.files) == 10
+    for name in exp.files:
+        got = api.read_jpeg(os.path.join(here, "jpeg", name))
+        assert got.shape == exp[name].shape and np.array_equal(got, exp[name]), name
+    with pytest.raises(api.HrtError) as e:
+        api.read_jpeg(os.path.join(here, "jpeg", "pil_progressive.jpg"))
+    assert "progressive" in str(e.value)
+    with pytest.raises(api.HrtError):
+        api.read_jpeg(os.path.join(here, "stb_written.png"))                      # not a JPEG
+    raw = open(os.path.join(here, "jpeg", "pil_420_restart.jpg"), "rb").read()
+    import tempfile
+    d = tempfile.mkdtemp()
+    for cut in (3, 40, len(raw) // 2):                                              # truncated files fail cleanly or decode what is there
+        open(os.path.join(d, "t.jpg"), "wb").write(raw[:cut])
+        try:
+            api.read_jpeg(os.path.join(d, "t.jpg"))
+        except api.HrtError:
+            pass
+
+
+def test_jpeg_image_texture_in_a_scene(built, tmp_path):
+    """ImageTexture with a .jpg path (texture.cpp:30-51 goes through stbi_load, which reads JPEG): the texels are the decoder's."""
+    import shutil
+    from hobbyraytracer_amd import api
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    shutil.copy(os.path.join(here, "jpeg", "pil_422.jpg"), tmp_path / "tex.jpg")
+    (tmp_path / "s.yaml").write_text("""
+film:
+    width: 8
+    height: 8
+    samples: 1
+    output: o.png
+camera:
+    position: [0, 0, 3]
+    look_at: [0, 0, 0]
+    up: [0, 1, 0]
+    fov: 50
+    aperture: 0
+    focal_distance: 3
+    background: [0.4, 0.5, 0.6]
+textures:
+  - name: photo
+    type: image
+    path: tex.jpg
+materials:
+  - name: m
+    type: lambertian
+    albedo: photo
+objects:
+  - type: sphere
+    center: [0, 0, 0]
+    radius: 1
+    material: m
+""")
+    hs = api.HostScene(str(tmp_path / "s.yaml"), str(tmp_path))
+    f = hs.flat
+    tex = [f.textures[i] for i in range(f.n_textures) if f.textures[i].kind == api.TEX_IMAGE][0]
+    assert (tex.width, tex.height) == (64, 48)
+    texels = np.ctypeslib.as_array(f.texels_u8, shape=(f.n_texels_u8,))[tex.offset:tex.offset + 64 * 48 * 3].reshape(48, 64, 3)
+    assert np.array_equal(texels, np.load(os.path.join(here, "jpeg_expected.npz"))["pil_422.jpg"])
