@@ -1,8 +1,8 @@
 // jpeg_lite.cpp — JPEG decoding for ImageTexture (texture.cpp:30-51 loads through stbi_load, which reads JPEG).
 //
-// Scope: what image textures come as — 8-bit baseline / extended-sequential Huffman JPEG, 1 (grey) or 3 (YCbCr, or RGB
-// when an Adobe marker says so) components, sampling factors 1 or 2 per axis, restart intervals, interleaved or
-// per-component scans.  Progressive, arithmetic-coded, 12-bit and CMYK files are refused with a message.
+// Scope: what image textures come as — 8-bit baseline / extended-sequential and PROGRESSIVE Huffman JPEG, 1 (grey) or 3
+// (YCbCr, or RGB when an Adobe marker says so) components, sampling factors 1 or 2 per axis, restart intervals,
+// interleaved or per-component scans.  Arithmetic-coded, lossless, 12-bit and CMYK files are refused with a message.
 //
 // Entropy decoding is the procedure of ITU T.81 Annex F (any conforming decoder yields the same coefficients).  From
 // the coefficients on, the PIXELS depend on the decoder, so those steps follow the arithmetic of stb_image v2.27, the
@@ -48,6 +48,7 @@ struct Component {
     int w2 = 0, h2 = 0;          // allocated (whole MCUs)
     int dc_pred = 0;
     std::vector<uint8_t> data;
+    std::vector<int16_t> coeff;  // progressive: all blocks' coefficients (natural order), (w2 / 8) x (h2 / 8) x 64
 };
 
 struct Decoder {
@@ -60,6 +61,8 @@ struct Decoder {
     int n_comp = 0, width = 0, height = 0, hmax = 1, vmax = 1, mcu_x = 0, mcu_y = 0;
     int restart_interval = 0;
     bool jfif = false; int adobe_transform = -1;
+    bool progressive = false;
+    int ss = 0, se = 63, ah = 0, al = 0, eob_run = 0;   // progressive scan parameters (T.81 G.1)
     bool rgb_ids = false;
     // bit reader
     uint32_t bitbuf = 0; int bitcnt = 0; bool hit_marker = false; int marker = -1;
@@ -172,11 +175,109 @@ bool decode_block(Decoder& z, Component& c, int16_t d[64]) {
     return true;
 }
 
+// Progressive scans (T.81 Annex G): DC first / refinement, AC first / refinement with end-of-band runs.  Coefficients
+// are stored UNquantised-times-2^Al; dequantisation happens once all scans are in (finish_progressive).
+bool prog_dc(Decoder& z, Component& c, int16_t* d) {
+    if (z.se != 0) return z.fail("DC and AC coefficients in one progressive scan");
+    if (z.ah == 0) {
+        std::memset(d, 0, 64 * sizeof(int16_t));
+        const int t = z.decode(z.dc[c.td]);
+        if (t < 0 || t > 15) return z.fail("bad huffman code");
+        c.dc_pred += t ? Decoder::extend(z.receive(t), t) : 0;
+        d[0] = (int16_t)(c.dc_pred * (1 << z.al));
+    } else if (z.bit()) d[0] = (int16_t)(d[0] + (int16_t)(1 << z.al));
+    return true;
+}
+bool prog_ac(Decoder& z, Component& c, int16_t* d) {
+    if (z.ss == 0) return z.fail("DC and AC coefficients in one progressive scan");
+    const HuffTable& ha = z.ac[c.ta];
+    if (z.ah == 0) {
+        if (z.eob_run) { --z.eob_run; return true; }
+        int k = z.ss;
+        do {
+            const int rs = z.decode(ha);
+            if (rs < 0) return z.fail("bad huffman code");
+            const int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (r < 15) {
+                    z.eob_run = 1 << r;
+                    if (r) z.eob_run += z.receive(r);
+                    --z.eob_run;
+                    break;
+                }
+                k += 16;
+            } else {
+                k += r;
+                if (k > 63) return z.fail("bad huffman code");
+                d[kZigzag[k++]] = (int16_t)(Decoder::extend(z.receive(s), s) * (1 << z.al));
+            }
+        } while (k <= z.se);
+        return true;
+    }
+    const int16_t bit = (int16_t)(1 << z.al);
+    auto refine = [&](int16_t& v) {                   // one correction bit for an already non-zero coefficient
+        if (z.bit() && (v & bit) == 0) v = (int16_t)(v > 0 ? v + bit : v - bit);
+    };
+    if (z.eob_run) {
+        --z.eob_run;
+        for (int k = z.ss; k <= z.se; ++k) { int16_t& v = d[kZigzag[k]]; if (v != 0) refine(v); }
+        return true;
+    }
+    int k = z.ss;
+    do {
+        const int rs = z.decode(ha);
+        if (rs < 0) return z.fail("bad huffman code");
+        int s = rs & 15, r = rs >> 4;
+        if (s == 0) {
+            if (r < 15) {
+                z.eob_run = (1 << r) - 1;
+                if (r) z.eob_run += z.receive(r);
+                r = 64;                                // run to the end of the band, refining on the way
+            }                                          // r == 15: sixteen zero coefficients, then go on
+        } else {
+            if (s != 1) return z.fail("bad huffman code");
+            s = z.bit() ? bit : -bit;
+        }
+        while (k <= z.se) {
+            int16_t& v = d[kZigzag[k++]];
+            if (v != 0) refine(v);
+            else {
+                if (r == 0) { v = (int16_t)s; break; }
+                --r;
+            }
+        }
+    } while (k <= z.se);
+    return true;
+}
+void finish_progressive(Decoder& z) {
+    for (int n = 0; n < z.n_comp; ++n) {
+        Component& c = z.comp[n];
+        const int bw = (c.w + 7) >> 3, bh = (c.hgt + 7) >> 3, cw = c.w2 / 8;
+        for (int j = 0; j < bh; ++j)
+            for (int i = 0; i < bw; ++i) {
+                int16_t* d = &c.coeff[64 * ((size_t)i + (size_t)j * cw)];
+                for (int k = 0; k < 64; ++k) d[k] = (int16_t)(d[k] * z.dequant[c.tq][k]);
+                idct_block(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, d);
+            }
+    }
+}
+
 bool decode_scan(Decoder& z, const int* order, int n_scan) {
     z.reset_bits();
+    z.eob_run = 0;
     for (int i = 0; i < z.n_comp; ++i) z.comp[i].dc_pred = 0;
     int todo = z.restart_interval ? z.restart_interval : 0x7fffffff;
     int16_t d[64];
+    // one block: baseline decodes and transforms it at once; progressive updates its stored coefficients
+    auto block = [&](Component& c, int bx, int by) -> bool {
+        if (!z.progressive) {
+            if (!decode_block(z, c, d)) return false;
+            idct_block(&c.data[(size_t)c.w2 * by * 8 + (size_t)bx * 8], c.w2, d);
+            return true;
+        }
+        int16_t* cd = &c.coeff[64 * ((size_t)bx + (size_t)by * (c.w2 / 8))];
+        return z.ss == 0 ? prog_dc(z, c, cd) : prog_ac(z, c, cd);
+    };
     auto restart_point = [&]() -> int {           // 1: continue after RSTn, 0: scan over, -1: error
         if (--todo > 0) return 1;
         // the entropy-coded segment ends at a marker; drop the padding bits
@@ -187,6 +288,7 @@ bool decode_scan(Decoder& z, const int* order, int n_scan) {
         }
         if (z.marker < 0xD0 || z.marker > 0xD7) return 0;
         z.reset_bits();
+        z.eob_run = 0;
         for (int i = 0; i < z.n_comp; ++i) z.comp[i].dc_pred = 0;
         todo = z.restart_interval ? z.restart_interval : 0x7fffffff;
         return 1;
@@ -196,8 +298,7 @@ bool decode_scan(Decoder& z, const int* order, int n_scan) {
         const int bw = (c.w + 7) >> 3, bh = (c.hgt + 7) >> 3;
         for (int j = 0; j < bh; ++j)
             for (int i = 0; i < bw; ++i) {
-                if (!decode_block(z, c, d)) return false;
-                idct_block(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, d);
+                if (!block(c, i, j)) return false;
                 if (z.restart_interval && restart_point() == 0) return true;
             }
         return true;
@@ -208,8 +309,7 @@ bool decode_scan(Decoder& z, const int* order, int n_scan) {
                 Component& c = z.comp[order[k]];
                 for (int y = 0; y < c.v; ++y)
                     for (int x = 0; x < c.h; ++x) {
-                        if (!decode_block(z, c, d)) return false;
-                        idct_block(&c.data[(size_t)c.w2 * ((j * c.v + y) * 8) + (size_t)(i * c.h + x) * 8], c.w2, d);
+                        if (!block(c, i * c.h + x, j * c.v + y)) return false;
                     }
             }
             if (z.restart_interval && restart_point() == 0) return true;
@@ -302,7 +402,8 @@ bool decodeJPEG(const uint8_t* bytes, size_t n_bytes, std::vector<uint8_t>& rgb,
                 }
                 break;
             }
-            case 0xC0: case 0xC1: {   // SOF0 / SOF1: baseline, extended sequential Huffman
+            case 0xC0: case 0xC1: case 0xC2: {   // SOF0 / SOF1 / SOF2: baseline, extended sequential, progressive (Huffman)
+                z.progressive = m == 0xC2;
                 if (have_frame) return bad("several frames");
                 if (z.u8() != 8) return bad("only 8-bit samples are supported");
                 z.height = z.u16(); z.width = z.u16(); z.n_comp = z.u8();
@@ -329,11 +430,11 @@ bool decodeJPEG(const uint8_t* bytes, size_t n_bytes, std::vector<uint8_t>& rgb,
                     c.hgt = (z.height * c.v + z.vmax - 1) / z.vmax;
                     c.w2 = z.mcu_x * c.h * 8; c.h2 = z.mcu_y * c.v * 8;
                     c.data.assign((size_t)c.w2 * c.h2, 0);
+                    if (z.progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);   // (w2 / 8) * (h2 / 8) * 64
                 }
                 have_frame = true;
                 break;
             }
-            case 0xC2: return bad("progressive JPEG is not supported (re-save as baseline)");
             case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
                 return bad("lossless / hierarchical / arithmetic-coded JPEG is not supported");
             case 0xDD: z.restart_interval = z.u16(); break;
@@ -350,10 +451,21 @@ bool decodeJPEG(const uint8_t* bytes, size_t n_bytes, std::vector<uint8_t>& rgb,
                     for (int k = 0; k < z.n_comp; ++k) if (z.comp[k].id == id) which = k;
                     if (which < 0) return bad("scan names an unknown component");
                     z.comp[which].td = tt >> 4; z.comp[which].ta = tt & 15;
-                    if (z.comp[which].td > 3 || z.comp[which].ta > 3 || !z.dc[z.comp[which].td].present || !z.ac[z.comp[which].ta].present ||
-                        !z.have_q[z.comp[which].tq])
-                        return bad("scan uses a table the file does not define");
+                    if (z.comp[which].td > 3 || z.comp[which].ta > 3 || !z.have_q[z.comp[which].tq]) return bad("scan uses a table the file does not define");
                     order[i] = which;
+                }
+                z.ss = z.u8(); z.se = z.u8();
+                { const int a = z.u8(); z.ah = a >> 4; z.al = a & 15; }
+                if (z.progressive) {
+                    if (z.ss > 63 || z.se > 63 || z.ss > z.se || z.ah > 13 || z.al > 13) return bad("bad progressive scan parameters");
+                    if (z.ss > 0 && ns != 1) return bad("interleaved AC scan");
+                } else {
+                    z.ss = 0; z.se = 63; z.ah = z.al = 0;
+                }
+                for (int i = 0; i < ns; ++i) {
+                    const Component& c = z.comp[order[i]];
+                    const bool need_dc = !z.progressive || (z.ss == 0 && z.ah == 0), need_ac = !z.progressive || z.ss > 0;
+                    if ((need_dc && !z.dc[c.td].present) || (need_ac && !z.ac[c.ta].present)) return bad("scan uses a table the file does not define");
                 }
                 z.p = seg_end;
                 if (!decode_scan(z, order, ns)) return bad("corrupt entropy-coded data");
@@ -366,6 +478,7 @@ bool decodeJPEG(const uint8_t* bytes, size_t n_bytes, std::vector<uint8_t>& rgb,
         z.p = seg_end;
     }
     if (!have_frame) return bad("no frame header");
+    if (z.progressive) finish_progressive(z);
 
     // ---- upsample + colour conversion, row by row
     w = z.width; h = z.height;

@@ -1,7 +1,6 @@
 """Generates tests/golden/jpeg/*.jpg and jpeg_expected.npz: small JPEG files of every flavour the product's decoder
 (hobbyraytracer_amd/host/jpeg_lite.cpp) accepts -- written by the reference's own stb_image_write (quality 95 -> 4:4:4,
-quality 60 -> 4:2:0) and by Pillow/libjpeg (4:2:2, 4:4:0, grey, restart intervals, odd sizes, a progressive file that must be
-refused) -- together with the pixels the REFERENCE's decoder, stbi_load(path, &w, &h, &n, 3) of the vendored stb_image.h
+quality 60 -> 4:2:0) and by Pillow/libjpeg (4:2:2, 4:4:0, grey, restart intervals, odd sizes, progressive files) -- together with the pixels the REFERENCE's decoder, stbi_load(path, &w, &h, &n, 3) of the vendored stb_image.h
 (oracle/_ref/libstbref.so), returns for them.  Fixtures are data.  Run in the build container (needs /root/reference and Pillow):
     python tests/golden/make_jpeg_fixtures.py"""
 import ctypes as C
@@ -44,7 +43,11 @@ if __name__ == "__main__":
     Image.fromarray(picture(9, 1)).save(os.path.join(out, "pil_420_1wide.jpg"), quality=75, subsampling=2); files["pil_420_1wide.jpg"] = None
     Image.fromarray(picture(33, 41)[:, :, 0]).save(os.path.join(out, "pil_grey.jpg"), quality=70); files["pil_grey.jpg"] = None
     pil.save(os.path.join(out, "pil_optimised_tables.jpg"), quality=60, subsampling=2, optimize=True); files["pil_optimised_tables.jpg"] = None
-    pil.save(os.path.join(out, "pil_progressive.jpg"), quality=80, progressive=True)    # must be refused by the product
+    pil.save(os.path.join(out, "pil_progressive.jpg"), quality=80, progressive=True); files["pil_progressive.jpg"] = None
+    pil.save(os.path.join(out, "pil_progressive_444_restart.jpg"), quality=92, subsampling=0, progressive=True, restart_marker_blocks=5)
+    files["pil_progressive_444_restart.jpg"] = None
+    Image.fromarray(picture(29, 35)[:, :, 1]).save(os.path.join(out, "pil_progressive_grey.jpg"), quality=50, progressive=True)
+    files["pil_progressive_grey.jpg"] = None
     exp = {}
     for name in files:
         w, h, n = C.c_int(), C.c_int(), C.c_int()

@@ -136,18 +136,16 @@ def test_pfm_film_dump_is_bit_exact(built, tmp_path):
 def test_jpeg_decoder_matches_the_references_stb(built):
     """hobbyraytracer_amd/host/jpeg_lite.cpp against stbi_load(path, ..., 3) of the stb_image.h the reference vendors
     (texture.cpp:34-36), on files written by the reference's stb_image_write and by libjpeg: 4:4:4, 4:2:2, 4:2:0 (odd sizes,
-    one pixel wide, restart intervals, optimised Huffman tables, quality 5 with clamping everywhere), grey.  Expected pixels
-    were produced by the reference's decoder itself (tests/golden/make_jpeg_fixtures.py).  Bit-exact; progressive is refused."""
+    one pixel wide, restart intervals, optimised Huffman tables, quality 5 with clamping everywhere), grey, progressive (colour
+    4:2:0, 4:4:4 with restarts, grey).  Expected pixels were produced by the reference's decoder itself
+    (tests/golden/make_jpeg_fixtures.py).  Bit-exact."""
     from hobbyraytracer_amd import api
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     exp = np.load(os.path.join(here, "jpeg_expected.npz"))
-    assert len(exp.files) == 10
+    assert len(exp.files) == 13
     for name in exp.files:
         got = api.read_jpeg(os.path.join(here, "jpeg", name))
         assert got.shape == exp[name].shape and np.array_equal(got, exp[name]), name
-    with pytest.raises(api.HrtError) as e:
-        api.read_jpeg(os.path.join(here, "jpeg", "pil_progressive.jpg"))
-    assert "progressive" in str(e.value)
     with pytest.raises(api.HrtError):
         api.read_jpeg(os.path.join(here, "stb_written.png"))                      # not a JPEG
     raw = open(os.path.join(here, "jpeg", "pil_420_restart.jpg"), "rb").read()
