@@ -238,41 +238,76 @@ bool readPNG(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h,
         else if (type == "IEND") break;
         p += 12 + (size_t)len;
     }
-    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) { err = "unsupported PNG (need 8-bit, non-interlaced)"; return false; }
-    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!ch) { err = "unsupported PNG colour type"; return false; }
-    const size_t row = (size_t)w * ch;
-    std::vector<uint8_t> raw((row + 1) * h);
+    // colour type -> channels; allowed bit depths (PNG spec table 11.1)
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                          (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                          ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (w <= 0 || h <= 0 || !ch || !depth_ok || interlace > 1) { err = "unsupported PNG (colour type / bit depth / interlace method)"; return false; }
+    if (ctype == 3 && plte.empty()) { err = "palette PNG without PLTE"; return false; }
+    // Adam7 passes (or the one pass of a non-interlaced file): origin and spacing of the pass's pixels
+    static const int kX0[7] = {0, 4, 0, 2, 0, 1, 0}, kY0[7] = {0, 0, 4, 0, 2, 0, 1}, kDX[7] = {8, 8, 4, 4, 2, 2, 1}, kDY[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int n_pass = interlace ? 7 : 1;
+    const int bits_pp = ch * depth;
+    const int fbpp = bits_pp >= 8 ? bits_pp / 8 : 1;           // filter unit: whole bytes per pixel, at least 1
+    size_t total = 0;
+    int pw[7], ph[7];
+    for (int k = 0; k < n_pass; ++k) {
+        pw[k] = interlace ? (w - kX0[k] + kDX[k] - 1) / kDX[k] : w;
+        ph[k] = interlace ? (h - kY0[k] + kDY[k] - 1) / kDY[k] : h;
+        if (pw[k] > 0 && ph[k] > 0) total += ((size_t)(((size_t)pw[k] * bits_pp + 7) / 8) + 1) * ph[k];
+    }
+    std::vector<uint8_t> raw(total);
     uLongf rl = (uLongf)raw.size();
     if (uncompress(raw.data(), &rl, idat.data(), (uLong)idat.size()) != Z_OK || rl != raw.size()) { err = "PNG inflate failed"; return false; }
-    std::vector<uint8_t> img(row * h);
-    for (int j = 0; j < h; ++j) {
-        const uint8_t* src = &raw[(row + 1) * j];
-        uint8_t* cur = &img[row * j];
-        const uint8_t* up = j ? &img[row * (j - 1)] : nullptr;
-        int ft = src[0];
-        for (size_t i = 0; i < row; ++i) {
-            int a = i >= (size_t)ch ? cur[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
-            int x = src[1 + i], v;
-            switch (ft) {
-                case 0: v = x; break;
-                case 1: v = x + a; break;
-                case 2: v = x + b; break;
-                case 3: v = x + ((a + b) >> 1); break;
-                case 4: { int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
-                          int pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); v = x + pr; break; }
-                default: err = "bad PNG filter"; return false;
+    rgb.assign((size_t)w * h * 3, 0);
+    // stb_image (the reference's decoder, texture.cpp:34-36) reduces 16-bit samples to their high byte and scales grey
+    // samples of 1 / 2 / 4 bits to 0..255; palette indices are looked up; alpha is dropped for the 3-channel request
+    const int grey_scale = depth == 1 ? 0xff : depth == 2 ? 0x55 : depth == 4 ? 0x11 : 1;
+    size_t at = 0;
+    std::vector<uint8_t> prev, cur;
+    for (int k = 0; k < n_pass; ++k) {
+        if (pw[k] <= 0 || ph[k] <= 0) continue;
+        const size_t row = ((size_t)pw[k] * bits_pp + 7) / 8;
+        prev.assign(row, 0); cur.assign(row, 0);
+        for (int j = 0; j < ph[k]; ++j) {
+            const uint8_t* src = &raw[at]; at += row + 1;
+            const int ft = src[0];
+            if (ft > 4) { err = "bad PNG filter"; return false; }
+            for (size_t i = 0; i < row; ++i) {
+                const int a = i >= (size_t)fbpp ? cur[i - fbpp] : 0, b = prev[i], c = i >= (size_t)fbpp ? prev[i - fbpp] : 0;
+                const int x = src[1 + i];
+                int v;
+                switch (ft) {
+                    case 0: v = x; break;
+                    case 1: v = x + a; break;
+                    case 2: v = x + b; break;
+                    case 3: v = x + ((a + b) >> 1); break;
+                    default: { const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                               v = x + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
+                }
+                cur[i] = (uint8_t)v;
             }
-            cur[i] = (uint8_t)v;
+            const int y = interlace ? kY0[k] + j * kDY[k] : j;
+            for (int i = 0; i < pw[k]; ++i) {
+                const int x = interlace ? kX0[k] + i * kDX[k] : i;
+                uint8_t* o = &rgb[((size_t)y * w + x) * 3];
+                auto sample = [&](int c) -> int {           // channel c of pixel i of this scanline, reduced to 8 bits
+                    if (depth == 8) return cur[(size_t)i * ch + c];
+                    if (depth == 16) return cur[((size_t)i * ch + c) * 2];
+                    const int bit = i * depth;                // 1, 2, 4 bits: one channel only
+                    return (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                };
+                if (ctype == 3) {
+                    const size_t idx = (size_t)sample(0) * 3;
+                    if (idx + 2 < plte.size()) { o[0] = plte[idx]; o[1] = plte[idx + 1]; o[2] = plte[idx + 2]; }
+                } else if (ctype == 0 || ctype == 4) {
+                    const int g = depth < 8 ? sample(0) * grey_scale : sample(0);
+                    o[0] = o[1] = o[2] = (uint8_t)g;
+                } else { o[0] = (uint8_t)sample(0); o[1] = (uint8_t)sample(1); o[2] = (uint8_t)sample(2); }
+            }
+            prev.swap(cur);
         }
-    }
-    rgb.resize((size_t)w * h * 3);
-    for (size_t i = 0; i < (size_t)w * h; ++i) {
-        const uint8_t* s = &img[i * ch];
-        uint8_t* o = &rgb[i * 3];
-        if (ctype == 0 || ctype == 4) { o[0] = o[1] = o[2] = s[0]; }
-        else if (ctype == 3) { size_t k = (size_t)s[0] * 3; if (k + 2 < plte.size()) { o[0] = plte[k]; o[1] = plte[k + 1]; o[2] = plte[k + 2]; } else o[0] = o[1] = o[2] = 0; }
-        else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
     }
     return true;
 }
