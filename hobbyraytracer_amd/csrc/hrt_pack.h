@@ -47,7 +47,12 @@ inline void pack_triangles(const hrt_flat_scene* f, std::vector<float>& pos, std
 //   grid : 2 x float4 per mesh  origin.xyz _ | step.xyz _          box = origin + q * step
 // Boxes are only ever used to CULL (acceptance uses the reference's exact leaf boxes, tri_box), so any superset
 // is valid: lo is rounded down and hi up until the decoded value, computed with the kernel's own fmaf, encloses
-// the fp32 box.  Empty children (min > max) keep their harmless never-smaller encoding lo=65535, hi=0.
+// the fp32 box -- and then one cell further.  The kernel evaluates t = q * (step / d) - (o - origin) / d, whose two terms
+// are as large as the box's distance from the GRID origin; near a far corner of a mesh with a huge dynamic range they
+// cancel and t is only good to ~1.2e-7 x the mesh extent = 0.008 cells (a chain of triangles growing from 1 to 1e10 lost
+// 13 % of its hits that way: tests/test_gpu_scenes.py::test_deep_bvh...).  A whole cell of slack (1.5e-5 x extent, the
+// size of the reference's own 1e-4 padding for the teapot) covers that with room for ray origins ~50 extents away.
+// Empty children (min > max) keep their harmless never-smaller encoding lo=65535, hi=0.
 inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, std::vector<float>& grids) {
     qnodes.assign((size_t)f->n_nodes * 8, 0u);
     grids.assign((size_t)f->n_meshes * 8, 0.0f);
@@ -78,12 +83,14 @@ inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, s
             long q = (long)std::floor(((double)v - (double)g[a]) / (double)g[4 + a]);
             q = q < 0 ? 0 : (q > 65535 ? 65535 : q);
             while (q > 0 && fmaf((float)q, g[4 + a], g[a]) > v) --q;
+            if (q > 0) --q;                                   // one more cell: see below
             return (uint32_t)q;
         };
         auto q_hi = [&](float v, int a) {
             long q = (long)std::ceil(((double)v - (double)g[a]) / (double)g[4 + a]);
             q = q < 0 ? 0 : (q > 65535 ? 65535 : q);
             while (q < 65535 && fmaf((float)q, g[4 + a], g[a]) < v) ++q;
+            if (q < 65535) ++q;
             return (uint32_t)q;
         };
         for (uint32_t i = 0; i < me.node_count; ++i) {

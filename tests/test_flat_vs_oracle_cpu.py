@@ -79,8 +79,8 @@ def test_bvh_structure(built, assets, scenes_dir, scene):
 @pytest.mark.parametrize("scene", ["teapot_scene.yaml", "bust_scene.yaml"])
 def test_packed_culling_nodes_enclose_the_fp32_boxes(built, assets, scenes_dir, tools, scene):
     """The 32-byte grid records the kernels traverse (hrt_pack.h pack_nodes) may only ever be LOOSER than the
-    fp32 child boxes of the ABI's hrt_bvh_node, decoded with the kernel's own fmaf; and not looser than two
-    grid cells, or culling would degrade silently."""
+    fp32 child boxes of the ABI's hrt_bvh_node, decoded with the kernel's own fmaf: by one to three grid cells (one cell
+    of deliberate slack for the cancellation in the kernel's slab arithmetic; more would degrade culling silently)."""
     _, FlatCpu = tools
     from hobbyraytracer_amd import api
     hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
@@ -101,7 +101,10 @@ def test_packed_culling_nodes_enclose_the_fp32_boxes(built, assets, scenes_dir, 
     empty = f32[:, :, 0, 0] > f32[:, :, 1, 0]
     ok = ~empty
     assert (dec_lo[ok] <= f32[:, :, 0][ok]).all() and (dec_hi[ok] >= f32[:, :, 1][ok]).all()
-    assert ((f32[:, :, 0][ok] - dec_lo[ok]) <= 2 * step + 1e-6).all() and ((dec_hi[ok] - f32[:, :, 1][ok]) <= 2 * step + 1e-6).all()
+    assert ((f32[:, :, 0][ok] - dec_lo[ok]) <= 3 * step + 1e-6).all() and ((dec_hi[ok] - f32[:, :, 1][ok]) <= 3 * step + 1e-6).all()
+    # ... and at least one whole cell looser on every side that is not clamped (the slack the kernel's cancellation needs)
+    inner = ok & (lo.min(-1) > 0) & (hi.max(-1) < 65535)
+    assert ((f32[:, :, 0][inner] - dec_lo[inner]) >= 0.99 * step).all() and ((dec_hi[inner] - f32[:, :, 1][inner]) >= 0.99 * step).all()
     children = np.stack([q[:, 3], q[:, 7]], 1).view(np.int32)
     assert np.array_equal(children, np.array([[n.child0, n.child1] for n in nodes], dtype=np.int32))
 
@@ -128,6 +131,26 @@ def test_image_does_not_depend_on_the_culling_tree(built, assets, scenes_dir, to
         films.append(a)
     for f in films[1:]:
         assert np.array_equal(f.view(np.uint32), films[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [60, 100])
+def test_mesh_with_a_huge_dynamic_range(built, tmp_path, tools, n):
+    """Triangles growing geometrically from size 1 to 1e10..1e17 in ONE mesh (and a BVH 18 / 26 levels deep): the grid
+    the culling boxes live on has cells of 1e5..1e12, the slab arithmetic cancels catastrophically near the small end, and
+    every hit must still be found (a version without the one-cell slack lost 13 % of them)."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import chain_scene
+    hs = api.HostScene(chain_scene(tmp_path, n, 1.5), str(tmp_path))
+    assert hs.bvh_depth(0) >= (17 if n == 60 else 25)
+    W, H, spp = 64, 48, 4
+    cam = hs.camera(W, H)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(W, H, spp, quirks=q, stats=True)
+        a, sa = FlatCpu(hs.flat_ptr).render_tile(cam, p)
+        b, sb = orc.World(hs.flat_ptr).render_tile(cam, p)
+        assert sb.mesh_hits > 500 and (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_degenerate_meshes(built, tmp_path, tools):

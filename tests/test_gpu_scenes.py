@@ -214,6 +214,36 @@ def test_world_larger_than_the_lds_tables(built, assets, tmp_path):
     dev.close()
 
 
+from tests.scene_helpers import chain_scene as _chain_scene  # noqa: E402
+
+
+@pytest.mark.parametrize("n,lo,hi", [(90, 21, 24), (100, 25, 32)])
+def test_deep_bvh_uses_the_larger_stack_variants(built, tmp_path, monkeypatch, n, lo, hi):
+    """BVH depth 21..24 -> the 24-entry LDS stack kernels, 25..32 -> the 32-entry ones (k_wf_ext and k_wf_tail are compiled
+    for 20 / 24 / 32 entries and chosen per mesh): same film and hit records as the oracle on all three render paths."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    hs = api.HostScene(_chain_scene(tmp_path, n, 1.5), str(tmp_path))
+    assert lo <= hs.bvh_depth(0) <= hi
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    W, H, spp = 64, 48, 4
+    cam = hs.camera(W, H)
+    ref, sr = world.render_tile(cam, api.default_params(W, H, spp, stats=True))
+    assert sr.mesh_hits > 500
+    for tail, mega in (("1", False), ("1000", False), ("1", True)):
+        monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+        img, st = dev.render_tile(cam, api.default_params(W, H, spp, stats=True, megakernel=mega))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (tail, mega)
+        assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits)
+    r = np.random.default_rng(3)
+    o = r.uniform([0, -0.5, 2], [40, 3, 14], (50000, 3)).astype(np.float32)
+    d = (r.uniform([0, -0.5, -0.2], [40, 0.5, 0.2], (50000, 3)) - o).astype(np.float32)
+    p = api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED)
+    g, c = dev.closest_hit(p, o, d), world.closest_hit(p, o, d)
+    assert (c["tri"] >= 0).sum() > 2000 and np.array_equal(g["tri"], c["tri"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+    dev.close()
+
+
 def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
     (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
