@@ -394,12 +394,22 @@ struct MeshRay {          // a ray in mesh space plus its per-ray constants
     TriRay tr;            // exact-arithmetic constants of the triangle test
     float idx, idy, idz;  // culling-only constants (free to differ from the reference: see header): 1/d,
     float gx, gy, gz;     // and the slab test in the mesh's node-grid coordinates: t = q * g - o_ (q = 16-bit grid index)
-    float ox, oy, oz;
+    float oxl, oxh, oyl, oyh, ozl, ozh;   // (o - origin) / d per axis, shifted for the LOW / HIGH face of a box (see mesh_ray_grid)
 };
 // box = origin + q * step  =>  t = (box - o) / d = q * (step / d) - (o - origin) / d
 __device__ inline void mesh_ray_grid(MeshRay& r, float4 origin, float4 step) {
     r.gx = r.idx * step.x; r.gy = r.idy * step.y; r.gz = r.idz * step.z;
-    r.ox = (r.o.x - origin.x) * r.idx; r.oy = (r.o.y - origin.y) * r.idy; r.oz = (r.o.z - origin.z) * r.idz;
+    const float ox = (r.o.x - origin.x) * r.idx, oy = (r.o.y - origin.y) * r.idy, oz = (r.o.z - origin.z) * r.idz;
+    // t = q * g - o_ carries the rounding of both terms: up to ~1.2e-7 of their magnitudes, which is no longer small
+    // against the boxes when the ray starts thousands of mesh extents away (a mesh seen from 1e5 units: 4 of 57 k hits
+    // were culled, at 1e6 units 1863).  The reference's own slab test rounds just as badly but is not what culls here,
+    // so every slab is widened by s = 4e-7 x (largest |q * g| + |o_|) at no cost in the loop: the face the ray ENTERS
+    // through gets o_ + s, the one it leaves through o_ - s, and which is which is the sign of g, known per ray.
+    const float sx = 4e-7f * (fabsf(r.gx) * 65535.0f + fabsf(ox)), sy = 4e-7f * (fabsf(r.gy) * 65535.0f + fabsf(oy)),
+                sz = 4e-7f * (fabsf(r.gz) * 65535.0f + fabsf(oz));
+    r.oxl = r.gx < 0 ? ox - sx : ox + sx; r.oxh = r.gx < 0 ? ox + sx : ox - sx;
+    r.oyl = r.gy < 0 ? oy - sy : oy + sy; r.oyh = r.gy < 0 ? oy + sy : oy - sy;
+    r.ozl = r.gz < 0 ? oz - sz : oz + sz; r.ozh = r.gz < 0 ? oz + sz : oz - sz;
 }
 __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4 origin, float4 step) {
     MeshRay r;
@@ -450,14 +460,14 @@ __device__ inline float trav_t_lo(float t_min, uint32_t quirks) { return (quirks
 // Slab test of BOTH child boxes of one 32-byte node against [t_lo, t_hi] (culling only).
 __device__ inline void node_test(const uint4& A, const uint4& B, const MeshRay& r, float t_lo, float t_hi,
                                  float& tn0, bool& h0, float& tn1, bool& h1) {
-    float a0 = fmaf((float)(A.x & 0xffffu), r.gx, -r.ox), a1 = fmaf((float)(A.x >> 16), r.gx, -r.ox);
-    float b0 = fmaf((float)(A.y & 0xffffu), r.gy, -r.oy), b1 = fmaf((float)(A.y >> 16), r.gy, -r.oy);
-    float c0 = fmaf((float)(A.z & 0xffffu), r.gz, -r.oz), c1 = fmaf((float)(A.z >> 16), r.gz, -r.oz);
+    float a0 = fmaf((float)(A.x & 0xffffu), r.gx, -r.oxl), a1 = fmaf((float)(A.x >> 16), r.gx, -r.oxh);
+    float b0 = fmaf((float)(A.y & 0xffffu), r.gy, -r.oyl), b1 = fmaf((float)(A.y >> 16), r.gy, -r.oyh);
+    float c0 = fmaf((float)(A.z & 0xffffu), r.gz, -r.ozl), c1 = fmaf((float)(A.z >> 16), r.gz, -r.ozh);
     tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_lo));
     float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), t_hi));
-    float e0 = fmaf((float)(B.x & 0xffffu), r.gx, -r.ox), e1 = fmaf((float)(B.x >> 16), r.gx, -r.ox);
-    float f0 = fmaf((float)(B.y & 0xffffu), r.gy, -r.oy), f1 = fmaf((float)(B.y >> 16), r.gy, -r.oy);
-    float g0 = fmaf((float)(B.z & 0xffffu), r.gz, -r.oz), g1 = fmaf((float)(B.z >> 16), r.gz, -r.oz);
+    float e0 = fmaf((float)(B.x & 0xffffu), r.gx, -r.oxl), e1 = fmaf((float)(B.x >> 16), r.gx, -r.oxh);
+    float f0 = fmaf((float)(B.y & 0xffffu), r.gy, -r.oyl), f1 = fmaf((float)(B.y >> 16), r.gy, -r.oyh);
+    float g0 = fmaf((float)(B.z & 0xffffu), r.gz, -r.ozl), g1 = fmaf((float)(B.z >> 16), r.gz, -r.ozh);
     tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_lo));
     float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), t_hi));
     h0 = tn0 <= tf0;
