@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -932,6 +933,18 @@ hrt_status validate(const hrt_flat_scene* f) {
             if (p.xf[k].kind < HRT_XF_TRANSLATE || p.xf[k].kind > HRT_XF_ROTATE_Y) return fail(HRT_ERR_INVALID, "wrapper kind out of range");
     }
     if (f->n_tris && (!f->tri_pos || !f->tri_nrm || !f->tri_uv)) return fail(HRT_ERR_INVALID, "triangle arrays missing");
+    // vertex positions feed the culling-node packer and the traversal's index arithmetic: NaN / inf there is refused, not rendered
+    for (uint64_t i = 0; i < (uint64_t)f->n_tris * 9; ++i)
+        if (!std::isfinite(f->tri_pos[i])) return fail(HRT_ERR_INVALID, "non-finite vertex position (triangle " + std::to_string(i / 9) + ")");
+    for (uint32_t i = 0; i < f->n_nodes; ++i) {
+        const hrt_bvh_node& n = f->nodes[i];
+        const float b[12] = {n.c0_min_x, n.c0_min_y, n.c0_min_z, n.c0_max_x, n.c0_max_y, n.c0_max_z, n.c1_min_x, n.c1_min_y, n.c1_min_z, n.c1_max_x, n.c1_max_y, n.c1_max_z};
+        for (int c = 0; c < 2; ++c) {
+            if (b[6 * c] > b[6 * c + 3]) continue;                      // empty child marker (+inf, -inf)
+            for (int k = 0; k < 6; ++k)
+                if (!std::isfinite(b[6 * c + k])) return fail(HRT_ERR_INVALID, "non-finite BVH box (node " + std::to_string(i) + ")");
+        }
+    }
     return HRT_OK;
 }
 

@@ -250,6 +250,7 @@ bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& e
         if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
             float x = 0, y = 0, z = 0;
             if (std::sscanf(s + 2, "%f %f %f", &x, &y, &z) < 3) { err = "OBJ: bad vertex at line " + std::to_string(lineNo); return false; }
+            if (!std::isfinite(x) || !std::isfinite(y) || !std::isfinite(z)) { err = "OBJ: non-finite vertex at line " + std::to_string(lineNo); return false; }
             v.push_back(x); v.push_back(y); v.push_back(z);
         } else if (s[0] == 'v' && s[1] == 't') {
             float a = 0, b = 0;

@@ -142,6 +142,14 @@ def test_scene_validation_refuses_malformed_input(built, assets, scenes_dir):
         api.DeviceScene(hs.flat_ptr, 0).render_tile(hs.camera(8, 8), api.default_params(8, 8, 1), (4, 4, 8, 8))   # tile outside the film
     with pytest.raises(api.HrtError):
         api.DeviceScene(hs.flat_ptr, 77)                                                                       # no such device
+    C.memmove(C.byref(flat), hs.flat_ptr, C.sizeof(api.FlatScene))
+    pos = (C.c_float * (flat.n_tris * 9))()
+    C.memmove(pos, flat.tri_pos, C.sizeof(pos))
+    pos[9 * 100 + 4] = float("nan")                                                                            # a NaN vertex coordinate
+    flat.tri_pos = C.cast(pos, C.POINTER(C.c_float))
+    with pytest.raises(api.HrtError) as e:
+        api.DeviceScene(flat, 0)
+    assert e.value.status == api.HRT_ERR_INVALID and "non-finite vertex position (triangle 100)" in str(e.value)
 
 
 def test_device_pointer_stream_api_with_torch(built, assets, scenes_dir):

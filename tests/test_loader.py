@@ -187,6 +187,17 @@ def test_additive_keys(built, assets, scenes_dir):
     assert [tris[2].xf[k].kind for k in range(tris[2].n_xforms)] == [api.XF_TRANSLATE, api.XF_SCALE, api.XF_ROTATE_QUAT]
 
 
+def test_obj_with_a_non_finite_vertex_is_refused(built, tmp_path):
+    """NaN / inf coordinates would poison the BVH builder and the culling-node packer: the importer says where."""
+    from hobbyraytracer_amd import api
+    for bad in ("nan 1 0", "0 inf 0", "1e39 0 0"):
+        (tmp_path / "t.obj").write_text(f"v 0 0 0\nv 1 0 0\nv {bad}\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+        with pytest.raises(api.HrtError) as e:
+            _load(tmp_path, BASE + "materials:\n  - name: m\n    type: lambertian\n    albedo: [1,1,1]\nobjects:\n  - type: mesh\n    path: t.obj\n    material: m\n",
+                  str(tmp_path))
+        assert "non-finite vertex at line 3" in str(e.value) or "could not import mesh" in str(e.value)
+
+
 def test_obj_import_matches_assimp_flags(built, tmp_path):
     """aiProcess_Triangulate | aiProcess_FlipUVs (mesh.cpp:56): fans, v -> 1-v, no generated normals
     (missing normals -> (0,0,0), mesh.cpp:83-90), missing uvs -> (0,0), negative indices."""
