@@ -426,6 +426,7 @@ __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4
     return r;
 }
 #define HRT_TRAV_DONE 0x7fffffff
+#define HRT_TIE_SELF 0x40000000   // TravState::best flag: the hit so far passes triangle.cpp:106-109 against its own t
 struct TravState {
     float closest;        // t_max, shrinking
     int best;             // closest accepted triangle so far (mesh-local index) or -1
@@ -527,10 +528,15 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
         TriEval ev;
         if (!tri_eval(r.tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;
         // triangle.cpp:106-109
-        if (ev.det < 0 && (ev.tScaled >= 0 || ev.tScaled < ts.closest * ev.det)) continue;
-        else if (ev.det > 0 && (ev.tScaled <= 0 || ev.tScaled > ts.closest * ev.det)) continue;
+        const float lim = ts.closest * ev.det;
+        bool farther = false;
+        if (ev.det < 0) { if (ev.tScaled >= 0) continue; farther = ev.tScaled < lim; }
+        else if (ev.det > 0) { if (ev.tScaled <= 0) continue; farther = ev.tScaled > lim; }
+        // `farther` rejects -- except for a rounding tie with the hit so far, see "Ties" below
+        if (farther && (ts.best < 0 || ts.selfhit || fabsf(ev.tScaled - lim) > 1e-6f * fabsf(lim))) continue;
         const float invDet = 1 / ev.det;
         const float t = ev.tScaled * invDet;
+        if (farther && t != ts.closest) continue;
         if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
         const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
         // accept_box costs six IEEE divisions and almost always passes.  Shortcut with the SAME outcome: if t is
@@ -551,13 +557,46 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
             bool take;
             if (!ts.selfhit) take = true;
             else if ((ord >> 1) != (ts.self_order >> 1)) take = (ord >> 1) < (ts.self_order >> 1);
-            else if (ord & 1u) take = !(t > ts.self_t);   // this is `right`, the kept one is `left`: bvh.cpp:75
-            else take = ts.self_t > t;                     // this is `left`: `right` survives only if not farther
-            if (take) { ts.self_order = ord; ts.self_tri = (int)ti; ts.self_t = t; }
+            else if (ord & 1u) {
+                // this is `right`, the kept one is `left`: bvh.cpp:75 hands `right` t_max = left's t, and `right` stays
+                // unless triangle.cpp:106-109 find it strictly beyond that
+                const float lim_l = ts.self_t * ev.det;
+                take = ev.det < 0 ? !(ev.tScaled < lim_l) : !(ev.tScaled > lim_l);
+            } else {
+                // this is `left`, the kept one is `right`, which the reference tests after this one: `right` survives
+                // if it is closer, or -- same t -- if it passes the comparison against its own rounded t
+                take = ts.self_t > t || (ts.self_t == t && !(ts.self_tri & HRT_TIE_SELF));
+            }
+            if (take) {
+                const float own = t * ev.det;
+                const bool self_now = ev.det < 0 ? !(ev.tScaled < own) : !(ev.tScaled > own);
+                ts.self_order = ord; ts.self_tri = (int)ti | (self_now ? HRT_TIE_SELF : 0); ts.self_t = t;
+            }
             if (!ts.selfhit) { ts.selfhit = true; ts.closest = t_min * 1.0001f; }
         } else if (!ts.selfhit) {
-            ts.closest = t;
-            ts.best = (int)ti;
+            // Ties.  triangle.cpp:106-109 keep a candidate X unless tScaled_X is strictly beyond t_best * det_X in fp32,
+            // and the reference meets the triangles in the fixed left-then-right order of ITS tree (bvh.cpp:74-75,
+            // ranked by tri_ref_order), this tree in another.  With t_X == t_best (duplicated or coplanar faces, a shared
+            // edge met to the last bit, far-away origins) the outcome of that sequential rule is, with "X self-passes"
+            // := X passes the comparison against its own rounded t:
+            //    both self-pass -> the one met LAST wins      neither -> the one met FIRST wins
+            //    only one self-passes -> that one wins, whatever the order
+            // X self-passes iff it was not `farther` here (t_best == t_X); the hit so far carries its own flag.
+            const bool self_x = !farther;
+            bool take = true;
+            if (ts.best >= 0 && !(t < ts.closest)) {
+                const bool self_b = (ts.best & HRT_TIE_SELF) != 0;
+                const uint32_t ord_x = (uint32_t)__float_as_int(bmn.w);
+                const uint32_t ord_b = (uint32_t)__float_as_int(tbox[2 * (ts.best & ~HRT_TIE_SELF)].w);
+                take = self_x != self_b ? self_x : (self_x ? ord_x > ord_b : ord_x < ord_b);
+            }
+            if (take) {
+                ts.closest = t;
+                // does this hit pass triangle.cpp:106-109 against its own t?
+                const float own = t * ev.det;
+                const bool self_now = farther ? false : (ev.det < 0 ? !(ev.tScaled < own) : !(ev.tScaled > own));
+                ts.best = (int)ti | (self_now ? HRT_TIE_SELF : 0);
+            }
         }
     }
     if (ts.sp > 0) { --ts.sp; ts.cur = stack[ts.sp * HRT_BLOCK]; }
@@ -565,9 +604,9 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
 }
 // Result of a finished traversal: winning triangle (or -1) and its t.
 __device__ inline int trav_result(const TravState& ts, float& t_out) {
-    if (ts.selfhit) { t_out = ts.self_t; return ts.self_tri; }
+    if (ts.selfhit) { t_out = ts.self_t; return ts.self_tri & ~HRT_TIE_SELF; }
     t_out = ts.closest;
-    return ts.best;
+    return ts.best < 0 ? -1 : (ts.best & ~HRT_TIE_SELF);
 }
 
 // Whole traversal for one lane (megakernel / test kernels).

@@ -162,7 +162,8 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
             }
             total.rays += pstats[g].rays; total.samples += pstats[g].samples; total.box_tests += pstats[g].box_tests;
             total.tri_tests += pstats[g].tri_tests; total.mesh_hits += pstats[g].mesh_hits; total.env_lookups += pstats[g].env_lookups;
-            total.launches += pstats[g].launches;
+            total.launches += pstats[g].launches; total.traversal_box_tests += pstats[g].traversal_box_tests;
+            total.traversal_tri_tests += pstats[g].traversal_tri_tests;
             if (pstats[g].kernel_ms > pass_kernel_ms) pass_kernel_ms = pstats[g].kernel_ms;
         }
         total.kernel_ms += pass_kernel_ms;

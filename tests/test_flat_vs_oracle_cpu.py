@@ -157,15 +157,17 @@ def test_ray_origins_far_from_the_mesh(built, assets, scenes_dir, tools):
     """Rays that start 10 .. 1e6 units from a 3-unit mesh.  fp32 leaves t good to 1e-7 x that distance, so (1) the
     culling arithmetic must allow for its own rounding (hrt_device.h mesh_ray_grid `slack`: without it 4 of 57 k hits were
     culled at 1e5 units and 1863 at 1e6) -- NO hit of the oracle may be lost and none invented; and (2) several triangles
-    round to the very same t: the reference keeps whichever its own tree visits last among such ties, we keep ours (DESIGN.md
-    "Residual differences") -- allowed here: a different triangle only where both report a hit whose t agrees to 4 ulp."""
+    round to the very same t: two-way ties are resolved exactly as the reference's own walk does (hrt_device.h trav_leaf
+    "Ties": none left up to 1e3 units); what remains from 1e5 units on are three-or-more-way near-ties whose outcome in the
+    reference depends on its visiting order in a non-transitive way (DESIGN.md "Ties") -- allowed here: a different triangle
+    only where both report a hit whose t agrees to 4 ulp."""
     orc, FlatCpu = tools
     from hobbyraytracer_amd import api
     hs = api.HostScene(f"{scenes_dir}/shiny_teapot.yaml", assets)
     flat, world = FlatCpu(hs.flat_ptr), orc.World(hs.flat_ptr)
     r = np.random.default_rng(5)
     n = 40000
-    for dist, max_ties in ((10.0, 2), (1e3, 5), (1e5, 400), (1e6, 4000)):
+    for dist, max_ties in ((10.0, 0), (1e3, 0), (1e5, 100), (1e6, 1500)):
         tgt = r.uniform([-1.8, 0.0, -1.0], [1.5, 1.6, 1.0], (n, 3))
         dirs = r.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         o = (tgt + dirs * dist).astype(np.float32)
@@ -178,6 +180,48 @@ def test_ray_origins_far_from_the_mesh(built, assets, scenes_dir, tools):
         assert diff.sum() <= max_ties, (dist, diff.sum())
         ulp = np.abs(g["t"][diff].view(np.int32).astype(np.int64) - c["t"][diff].view(np.int32).astype(np.int64))
         assert (ulp <= 4).all(), (dist, ulp.max())
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, (0, 0, 0)), (1e-3, (0, 0, 0)), (1e4, (0, 0, 0)), (1.0, (1e3, -2e3, 5e2)), (1e6, (1e7, 0, 0))])
+@pytest.mark.parametrize("kind", ["plain", "degenerate", "dup", "flat"])
+def test_triangle_soups_ties_and_zero_area_faces(built, tmp_path, tools, kind, scale, offset):
+    """Triangle soups at scene scales 1e-3 .. 1e6 and up to 1e7 units from the origin.  `dup`: every ray that meets a
+    duplicated face finds two hits with the very same t; which copy the reference keeps follows from its own walk order
+    and from whether the face passes triangle.cpp:106-109 against its own rounded t (hrt_device.h trav_leaf "Ties") -- the
+    copies carry opposite normals, so film AND triangle index must agree.  `degenerate`: zero-area faces never hit and
+    never poison a leaf.  `flat`: coplanar overlapping faces -- three-way near-ties are visiting-order dependent in the
+    reference (DESIGN.md "Ties"): hit/miss and t must agree, the triangle index may differ in a few rays."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import soup_scene
+    path, ctr = soup_scene(tmp_path, kind, scale, offset)
+    hs = api.HostScene(path, str(tmp_path))
+    W = H = 48
+    p = api.default_params(W, H, 4, quirks=api.QUIRKS_FIXED, stats=True)
+    flat, world = FlatCpu(hs.flat_ptr), orc.World(hs.flat_ptr)
+    if kind != "flat":
+        a, sa = flat.render_tile(hs.camera(W, H), p)
+        b, sb = world.render_tile(hs.camera(W, H), p)
+        assert (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits) and sb.mesh_hits > 300
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    r = np.random.default_rng(3)
+    n = 20000
+    tgt = ctr + r.uniform(-1.2, 1.2, (n, 3)) * scale
+    dirs = r.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    o = (tgt + dirs * 4 * scale).astype(np.float32)
+    d = (-dirs * scale).astype(np.float32)
+    g, c = flat.closest_hit(p, o, d), world.closest_hit(p, o, d)
+    if kind == "flat" and scale >= 1e4:
+        # triangle.cpp:133-151 pads a flat box by a fixed 1e-4: at z = 2500 that rounds away, the box has no thickness,
+        # AABB::hit (aabb.h:35) fails for every ray and the reference never shows such a mesh.  Neither do we.
+        assert (c["tri"] >= 0).sum() == 0
+    else:
+        assert (c["tri"] >= 0).sum() > 3000
+    assert np.array_equal(g["tri"] >= 0, c["tri"] >= 0)
+    diff = g["tri"] != c["tri"]
+    assert diff.sum() <= (150 if kind == "flat" else 0), diff.sum()
+    ulp = np.abs(g["t"][diff].view(np.int32).astype(np.int64) - c["t"][diff].view(np.int32).astype(np.int64))
+    assert (ulp <= 4).all()
 
 
 def test_degenerate_meshes(built, tmp_path, tools):

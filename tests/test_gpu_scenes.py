@@ -252,6 +252,38 @@ def test_deep_bvh_uses_the_larger_stack_variants(built, tmp_path, monkeypatch, n
     dev.close()
 
 
+@pytest.mark.parametrize("kind", ["dup", "degenerate"])
+def test_triangle_soup_ties_and_zero_area_faces(built, tmp_path, monkeypatch, kind):
+    """Duplicated faces whose copies carry opposite normals (every hit on them is an exact tie: the reference's walk order
+    decides, hrt_device.h trav_leaf "Ties") and zero-area faces: film and hit records as the oracle, on all three paths."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import soup_scene
+    path, ctr = soup_scene(tmp_path, kind)
+    hs = api.HostScene(path, str(tmp_path))
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    W = H = 48
+    cam = hs.camera(W, H)
+    for quirks in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(W, H, 4, quirks=quirks, stats=True))
+        assert sr.mesh_hits > 300
+        for tail, mega in (("1", False), ("1000", False), ("1", True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(W, H, 4, quirks=quirks, stats=True, megakernel=mega))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (quirks, tail, mega)
+            assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits)
+    r = np.random.default_rng(3)
+    n = 50000
+    tgt = ctr + r.uniform(-1.2, 1.2, (n, 3))
+    dirs = r.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    o, d = (tgt + dirs * 4).astype(np.float32), (-dirs).astype(np.float32)
+    p = api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED)
+    g, c = dev.closest_hit(p, o, d), world.closest_hit(p, o, d)
+    assert (c["tri"] >= 0).sum() > 10000 and np.array_equal(g["tri"], c["tri"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+    assert np.array_equal(g["normal"].view(np.uint32), c["normal"].view(np.uint32))
+    dev.close()
+
+
 def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
     (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
