@@ -715,11 +715,25 @@ __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o,
 __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, DRec& rec) {
     const hrt_prim& pr = sc.lprims[wh.prim];
     vec3 lo = o, ld = d;
-    vec3 dirs[HRT_MAX_XFORMS];
     const int n = pr.n_xforms;
-#pragma unroll
-    for (int k = 0; k < HRT_MAX_XFORMS; ++k) {
-        if (k < n) { xf_apply(pr.xf[k], lo, ld, quirks); dirs[k] = ld; }
+    // The wrapper chain, outermost first; d_k = the direction wrapper k handed to its child.  Written as NESTED ifs on
+    // purpose: the flat form (`#pragma unroll for k: if (k < n) xf_apply(xf[k])`, four independent predicated blocks)
+    // is miscompiled by hipcc 7.2 for gfx950 inside k_wf_shade / k_wf_tail -- a per-lane chain of exactly three
+    // wrappers came back with a wrong rec.p (found by tests/scene_helpers.py random_world; the megakernel, which inlines
+    // the same source, was right; adding a printf made it right).  Nested ifs, a runtime loop and a noinline function
+    // were all correct; this form costs nothing (k_wf_shade 21.2 ms vs 21.5 ms on the headline frame).
+    // tests/test_gpu_scenes.py::test_wrapper_chains_of_every_length pins it.
+    vec3 d0 = d, d1 = d, d2 = d, d3 = d;
+    static_assert(HRT_MAX_XFORMS == 4, "world_rec spells the wrapper chain out");
+    if (n > 0) {
+        xf_apply(pr.xf[0], lo, ld, quirks); d0 = ld;
+        if (n > 1) {
+            xf_apply(pr.xf[1], lo, ld, quirks); d1 = ld;
+            if (n > 2) {
+                xf_apply(pr.xf[2], lo, ld, quirks); d2 = ld;
+                if (n > 3) { xf_apply(pr.xf[3], lo, ld, quirks); d3 = ld; }
+            }
+        }
     }
     rec.mat = pr.material;
     rec.frontFace = true;
@@ -731,9 +745,15 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
         rec.t = wh.t; rec.p = lo + (wh.t * ld); rec.normal = vec3(1, 0, 0); rec.frontFace = true; rec.u = 0.0f; rec.v = 0.0f;
     } else if (kind == HRT_PRIM_TRIANGLE) triangle_rec(pr.p, lo, ld, rec);
     else rect_rec(rect_axis(kind), pr.p, lo, ld, wh.t, rec);
-#pragma unroll
-    for (int k = HRT_MAX_XFORMS - 1; k >= 0; --k) {
-        if (k < n) xf_unapply(pr.xf[k], rec, dirs[k]);
+    if (n > 0) {   // innermost wrapper first, nested for the same reason
+        if (n > 1) {
+            if (n > 2) {
+                if (n > 3) xf_unapply(pr.xf[3], rec, d3);
+                xf_unapply(pr.xf[2], rec, d2);
+            }
+            xf_unapply(pr.xf[1], rec, d1);
+        }
+        xf_unapply(pr.xf[0], rec, d0);
     }
 }
 

@@ -57,3 +57,102 @@ def soup_scene(tmp_path, kind, scale=1.0, offset=(0.0, 0.0, 0.0), n=300, seed=7)
         "materials:\n  - name: m\n    type: metal\n    albedo: [0.8, 0.6, 0.5]\n    roughness: 0.2\n"
         "objects:\n  - type: mesh\n    path: soup.obj\n    material: m\n")
     return str(tmp_path / "soup.yaml"), ctr
+
+
+def _v3(v): return "[%.9g, %.9g, %.9g]" % tuple(v)
+def random_world(tmp_path, seed, extreme):
+    """A random world of analytic primitives (spheres, rects, boxes, media, free triangles) on a 0.5 lattice, so that
+    coplanar / coincident surfaces are common, with random transform chains and materials and a few objects listed twice
+    with another material (exact ties between primitives).  `extreme` adds degenerate parameters: zero / negative radii and
+    box dimensions, reversed or empty rect ranges, negative and huge scales, ior 1 / 0.5 / 1e-3 / 50, roughness 2.5,
+    medium densities 0 / 1e-6 / 1e4 / -1."""
+    import re
+    import numpy as np
+    d = tmp_path
+    r=np.random.default_rng(seed)
+    mats=[]
+    def col(): return r.uniform(0,1,3)
+    names=[]
+    for i in range(8):
+        k=r.integers(0,7)
+        n="m%d"%i; names.append(n)
+        if k==0: mats.append(f"  - name: {n}\n    type: lambertian\n    albedo: {_v3(col())}\n")
+        elif k==1: mats.append(f"  - name: {n}\n    type: metal\n    albedo: {_v3(col())}\n    roughness: %.6g\n"%(r.choice([0,0.1,0.5,1.0,2.5]) if extreme else r.uniform(0,0.6)))
+        elif k==2: mats.append(f"  - name: {n}\n    type: dielectric\n    ior: %.6g\n"%(r.choice([1.0,1.5,0.5,2.4,1e-3,50]) if extreme else r.uniform(1.1,2)))
+        elif k==3: mats.append(f"  - name: {n}\n    type: diffuse_light\n    albedo: {_v3(col())}\n    strength: %.6g\n"%r.uniform(0.5,8))
+        elif k==4: mats.append(f"  - name: {n}\n    type: pbr\n    albedo: {_v3(col())}\n    metalness: %.6g\n    roughness: %.6g\n"%(r.uniform(0,1),r.uniform(0,1)))
+        elif k==5: mats.append(f"  - name: {n}\n    type: uv_test\n")
+        else: mats.append(f"  - name: {n}\n    type: lambertian\n    albedo: chk\n")
+    objs=[]
+    grid=lambda: np.round(r.uniform(-2,2,3)*2)/2   # coincidences on a 0.5 lattice
+    def xf():
+        if r.random()<0.5: return ""
+        s="    transform:\n"
+        if r.random()<0.4: s+="        rotate_y: %.6g\n"%r.choice([0,90,45,r.uniform(-180,180)])
+        if r.random()<0.3: s+="        rotate: %s\n"%_v3(r.uniform(-90,90,3))
+        if r.random()<0.4: s+="        scale: %s\n"%_v3(r.choice([0.5,1,2,1.5],3) if not extreme else r.choice([0.5,1,2,-1,1e-3,100],3))
+        if r.random()<0.6: s+="        translate: %s\n"%_v3(grid())
+        return s if s!="    transform:\n" else ""
+    for i in range(r.integers(3,14)):
+        k=r.integers(0,8); m=names[r.integers(0,8)]
+        if k==0:
+            rad=r.choice([0.5,1.0,0.25]) if not extreme else r.choice([0.5,1.0,0,-0.5,1e-4,30])
+            objs.append(f"  - type: sphere\n    center: {_v3(grid())}\n    radius: %.6g\n    material: {m}\n"%rad+xf())
+        elif k in (1,2,3):
+            t=["xy_rect","xz_rect","yz_rect"][k-1]; ax={"xy_rect":"xy","xz_rect":"xz","yz_rect":"yz"}[t]
+            a=np.sort(np.round(r.uniform(-3,3,2)*2)/2); b=np.sort(np.round(r.uniform(-3,3,2)*2)/2)
+            if extreme and r.random()<0.3: a=a[::-1]
+            if extreme and r.random()<0.2: b[1]=b[0]
+            objs.append(f"  - type: {t}\n    {ax[0]}: [%.6g, %.6g]\n    {ax[1]}: [%.6g, %.6g]\n    k: %.6g\n    material: {m}\n"%(a[0],a[1],b[0],b[1],np.round(r.uniform(-2,2)*2)/2)+xf())
+        elif k==4:
+            c=grid(); dm=r.choice([0.5,1,2],3) if not extreme else r.choice([0.5,1,0,-1,2],3)
+            objs.append(f"  - type: box\n    center: {_v3(c)}\n    dimensions: {_v3(dm)}\n    material: {m}\n"+xf())
+        elif k==5:
+            lo=grid(); hi=lo+r.choice([0.5,1,1.5],3)
+            objs.append(f"  - type: box\n    min: {_v3(lo)}\n    max: {_v3(hi)}\n    material: {m}\n"+xf())
+        elif k==6:
+            dens=r.uniform(0.2,3) if not extreme else r.choice([0,1e-6,1,1e4,-1])
+            if r.random()<0.5: bnd=f"        type: sphere\n        center: {_v3(grid())}\n        radius: %.6g\n"%r.choice([0.5,1,1.5])
+            else: bnd=f"        type: box\n        center: {_v3(grid())}\n        dimensions: {_v3(r.choice([1,2],3))}\n"
+            objs.append(f"  - type: constant_medium\n    boundary:\n{bnd}    density: %.6g\n    colour: {_v3(col())}\n"%dens+xf())
+        else:
+            objs.append(f"  - type: triangle\n    v0: {_v3(grid())}\n    v1: {_v3(grid())}\n    v2: {_v3(grid())}\n    material: {m}\n"+xf())
+    # duplicates: repeat some objects with another material (exact ties at world level)
+    for j in range(r.integers(0,3)):
+        o=objs[r.integers(0,len(objs))]
+        if "material:" in o:
+            objs.insert(r.integers(0,len(objs)+1), re.sub(r"material: m\d", "material: "+names[r.integers(0,8)], o))
+    cam=r.uniform(-1,1,3)*np.array([3,2,1])+np.array([0,1,7])
+    y=("film:\n    width: 40\n    height: 40\n    samples: 4\n    output: o.png\n"
+       f"camera:\n    position: {_v3(cam)}\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: %.6g\n    focal_distance: 7\n    background: {_v3(col())}\n"%r.choice([0,0.1])+
+       "textures:\n  - name: chk\n    type: checkered\n    even: [0.9, 0.9, 0.9]\n    odd: [0.1, 0.3, 0.1]\n"
+       "materials:\n"+"".join(mats)+"objects:\n"+"".join(objs))
+    open(d/"f.yaml","w").write(y)
+    return str(d/"f.yaml")
+
+
+def wrapper_chain_scene(tmp_path, chain):
+    """One object of every kind (sphere, box, rect, free triangle, medium, mesh), each under the SAME wrapper chain:
+    `chain` is a subset of "YQST" (rotate_y, rotate, scale, translate; the loader nests them in that order, scene.cpp:334-354),
+    so every chain length 0..4 = HRT_MAX_XFORMS can be asked for."""
+    xf = {"Y": "        rotate_y: 35\n", "Q": "        rotate: [-53.4, -38.9, -33.5]\n", "S": "        scale: [1, 1.5, 0.75]\n",
+          "T": "        translate: [0.25, -0.5, 0.5]\n"}
+    t = ("    transform:\n" + "".join(xf[c] for c in chain)) if chain else ""
+    with open(tmp_path / "quad.obj", "w") as f:
+        f.write("v -0.6 -0.6 0\nv 0.6 -0.6 0\nv 0.6 0.6 0.2\nv -0.6 0.6 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n")
+    (tmp_path / "chain.yaml").write_text(
+        "film:\n    width: 48\n    height: 48\n    samples: 4\n    output: o.png\n"
+        "camera:\n    position: [0.5, 1.5, 9]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: 0\n"
+        "    focal_distance: 9\n    background: [0.6, 0.7, 0.9]\n"
+        "materials:\n  - name: a\n    type: lambertian\n    albedo: [0.8, 0.4, 0.3]\n  - name: b\n    type: metal\n    albedo: [0.8, 0.8, 0.7]\n"
+        "    roughness: 0.1\n  - name: c\n    type: uv_test\n  - name: g\n    type: dielectric\n    ior: 1.5\n"
+        "objects:\n"
+        "  - type: sphere\n    center: [-2, 1.2, 0]\n    radius: 0.7\n    material: g\n" + t +
+        "  - type: box\n    center: [0, 1.2, 0]\n    dimensions: [1, 1, 1]\n    material: c\n" + t +
+        "  - type: xy_rect\n    x: [1.4, 2.6]\n    y: [0.6, 1.8]\n    k: 0\n    material: b\n" + t +
+        "  - type: triangle\n    v0: [-2.6, -1.6, 0]\n    v1: [-1.4, -1.6, 0.3]\n    v2: [-2, -0.4, 0]\n    material: a\n" + t +
+        "  - type: constant_medium\n    boundary:\n        type: sphere\n        center: [0, -1, 0]\n        radius: 0.7\n    density: 1.5\n"
+        "    colour: [0.2, 0.8, 0.3]\n" + t +
+        "  - type: mesh\n    path: quad.obj\n    material: b\n" + ("    transform:\n" + "".join(xf[c] for c in chain if c != "T") + "        translate: [2, -1, 0]\n") +
+        "  - type: xz_rect\n    x: [-6, 6]\n    z: [-6, 6]\n    k: -2.2\n    material: a\n")
+    return str(tmp_path / "chain.yaml")

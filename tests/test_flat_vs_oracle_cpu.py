@@ -224,6 +224,25 @@ def test_triangle_soups_ties_and_zero_area_faces(built, tmp_path, tools, kind, s
     assert (ulp <= 4).all()
 
 
+@pytest.mark.parametrize("extreme", [0, 1])
+def test_random_worlds_of_analytic_primitives(built, tmp_path, tools, extreme):
+    """tests/scene_helpers.py random_world: coincident / coplanar primitives, duplicated objects with other materials,
+    random transform chains, and (extreme) degenerate parameters -- the flattened scene renders the oracle's film bit for
+    bit, with both quirk sets.  (The same generator ran 210 seeds clean when this test was written; the GPU twin in
+    test_gpu_scenes.py runs more seeds than this one.)"""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import random_world
+    for seed in range(8):
+        hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme), str(tmp_path))
+        for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+            p = api.default_params(40, 40, 4, quirks=q, stats=True)
+            a, sa = FlatCpu(hs.flat_ptr).render_tile(hs.camera(40, 40), p)
+            b, sb = orc.World(hs.flat_ptr).render_tile(hs.camera(40, 40), p)
+            assert sa.rays == sb.rays, (seed, q)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, q)
+
+
 def test_degenerate_meshes(built, tmp_path, tools):
     """Single triangle (root leaf) and the two-triangle case: flattened result == oracle."""
     orc, FlatCpu = tools

@@ -284,6 +284,58 @@ def test_triangle_soup_ties_and_zero_area_faces(built, tmp_path, monkeypatch, ki
     dev.close()
 
 
+@pytest.mark.parametrize("extreme", [0, 1])
+def test_random_worlds_of_analytic_primitives(built, tmp_path, monkeypatch, extreme):
+    """tests/scene_helpers.py random_world (coincident surfaces, duplicated objects, transform chains; `extreme`: zero /
+    negative radii and dimensions, reversed rect ranges, ior 1e-3..50, densities 0 / 1e4 / -1 ...): 24 seeds x 2 quirk sets,
+    wavefront pipeline (with and without the task-persistent tail) and megakernel, film bit-identical to the oracle."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import random_world
+    rendered = 0
+    for seed in range(24):
+        hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme), str(tmp_path))
+        try:
+            dev = api.DeviceScene(hs.flat_ptr, 0)
+        except api.HrtError as e:   # hrt_scene_create refuses what would divide by zero on the device (density <= 0)
+            assert extreme and "density" in str(e), (seed, str(e))
+            continue
+        rendered += 1
+        world = orc.World(hs.flat_ptr)
+        cam = hs.camera(40, 40)
+        for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+            ref, sr = world.render_tile(cam, api.default_params(40, 40, 4, quirks=q, stats=True))
+            for tail, mega in (("1", False), ("1000", False), ("1", True)):
+                monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+                img, st = dev.render_tile(cam, api.default_params(40, 40, 4, quirks=q, stats=True, megakernel=mega))
+                assert st.rays == sr.rays, (seed, q, tail, mega)
+                assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (seed, q, tail, mega)
+        dev.close()
+    assert rendered >= 12
+
+
+@pytest.mark.parametrize("chain", ["", "Y", "Q", "S", "T", "YQ", "QS", "ST", "YQS", "YQT", "QST", "YST", "YQST"])
+def test_wrapper_chains_of_every_length(built, tmp_path, monkeypatch, chain):
+    """Every primitive kind under wrapper chains of length 0..4.  Pins a compiler problem found by the random worlds:
+    world_rec's chain walk, written as four independent predicated blocks, came back with a wrong rec.p for chains of
+    exactly three wrappers inside k_wf_shade / k_wf_tail only (hrt_device.h world_rec)."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import wrapper_chain_scene
+    hs = api.HostScene(wrapper_chain_scene(tmp_path, chain), str(tmp_path))
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    W = H = 48
+    cam = hs.camera(W, H)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(W, H, 4, quirks=q, stats=True))
+        for tail, mega, stats in (("1", False, True), ("1000", False, True), ("1000", False, False), ("1", False, False), ("1", True, True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(W, H, 4, quirks=q, stats=stats, megakernel=mega))
+            assert st.rays == sr.rays, (q, tail, mega, stats)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (q, tail, mega, stats)
+    dev.close()
+
+
 def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
     (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
