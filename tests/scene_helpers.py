@@ -60,12 +60,14 @@ def soup_scene(tmp_path, kind, scale=1.0, offset=(0.0, 0.0, 0.0), n=300, seed=7)
 
 
 def _v3(v): return "[%.9g, %.9g, %.9g]" % tuple(v)
-def random_world(tmp_path, seed, extreme):
+def random_world(tmp_path, seed, extreme, meshes=False):
     """A random world of analytic primitives (spheres, rects, boxes, media, free triangles) on a 0.5 lattice, so that
     coplanar / coincident surfaces are common, with random transform chains and materials and a few objects listed twice
     with another material (exact ties between primitives).  `extreme` adds degenerate parameters: zero / negative radii and
     box dimensions, reversed or empty rect ranges, negative and huge scales, ior 1 / 0.5 / 1e-3 / 50, roughness 2.5,
-    medium densities 0 / 1e-6 / 1e4 / -1."""
+    medium densities 0 / 1e-6 / 1e4 / -1.  `meshes` inserts 1..3 triangle meshes (a soup, a smooth-shaded sphere, a lattice-
+    aligned grid that is coplanar with rects and box faces) at random places of the object list, under wrapper chains of their
+    own: the wavefront pipeline walks the list mesh by mesh, analytic primitives in between (k_wf_pre)."""
     import re
     import numpy as np
     d = tmp_path
@@ -122,6 +124,48 @@ def random_world(tmp_path, seed, extreme):
         o=objs[r.integers(0,len(objs))]
         if "material:" in o:
             objs.insert(r.integers(0,len(objs)+1), re.sub(r"material: m\d", "material: "+names[r.integers(0,8)], o))
+    if meshes:
+        rm = np.random.default_rng(10**6 + seed)          # its own stream: the analytic part of a seed stays what it was
+        def xfm():
+            t = "    transform:\n"
+            if rm.random() < 0.4: t += "        rotate_y: %.6g\n" % rm.choice([90, 45, rm.uniform(-180, 180)])
+            if rm.random() < 0.4: t += "        rotate: %s\n" % _v3(rm.uniform(-90, 90, 3))
+            if rm.random() < 0.4: t += "        scale: %s\n" % _v3(rm.choice([0.5, 1, 2, 1.5], 3))
+            if rm.random() < 0.7: t += "        translate: %s\n" % _v3(np.round(rm.uniform(-2, 2, 3) * 2) / 2)
+            return t if t != "    transform:\n" else ""
+        for i in range(int(rm.integers(1, 4))):
+            kind = int(rm.integers(0, 3))
+            with open(d / ("fmesh%d.obj" % i), "w") as f:
+                if kind == 0:      # soup
+                    n = int(rm.integers(1, 120))
+                    tri = rm.uniform(-1, 1, (n, 1, 3)) + rm.normal(scale=0.3, size=(n, 3, 3))
+                    f.write("vn 0 1 0\n")
+                    for t in tri:
+                        for v in t: f.write("v %.9g %.9g %.9g\n" % tuple(v))
+                    for k in range(n): f.write("f %d//1 %d//1 %d//1\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+                elif kind == 1:    # smooth sphere
+                    nu, nv = int(rm.integers(3, 12)), int(rm.integers(2, 8))
+                    rad = float(rm.choice([0.5, 1.0]))
+                    for a in range(nv + 1):
+                        for b in range(nu):
+                            th, ph = np.pi * a / nv, 2 * np.pi * b / nu
+                            nn = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+                            f.write("v %.9g %.9g %.9g\nvn %.9g %.9g %.9g\n" % (tuple(nn * rad) + tuple(nn)))
+                    for a in range(nv):
+                        for b in range(nu):
+                            i0, i1 = a * nu + b + 1, a * nu + (b + 1) % nu + 1
+                            j0, j1 = i0 + nu, i1 + nu
+                            f.write("f %d//%d %d//%d %d//%d\nf %d//%d %d//%d %d//%d\n" % (i0, i0, j0, j0, j1, j1, i0, i0, j1, j1, i1, i1))
+                else:              # lattice-aligned grid in the plane z = 0
+                    g = int(rm.integers(1, 6))
+                    f.write("vn 0 0 1\n")
+                    for a in range(g + 1):
+                        for b in range(g + 1): f.write("v %.9g %.9g 0\n" % (0.5 * b - 1, 0.5 * a - 1))
+                    for a in range(g):
+                        for b in range(g):
+                            i0 = a * (g + 1) + b + 1
+                            f.write("f %d//1 %d//1 %d//1\nf %d//1 %d//1 %d//1\n" % (i0, i0 + 1, i0 + g + 2, i0, i0 + g + 2, i0 + g + 1))
+            objs.insert(int(rm.integers(0, len(objs) + 1)), "  - type: mesh\n    path: fmesh%d.obj\n    material: %s\n" % (i, names[int(rm.integers(0, 8))]) + xfm())
     cam=r.uniform(-1,1,3)*np.array([3,2,1])+np.array([0,1,7])
     y=("film:\n    width: 40\n    height: 40\n    samples: 4\n    output: o.png\n"
        f"camera:\n    position: {_v3(cam)}\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: %.6g\n    focal_distance: 7\n    background: {_v3(col())}\n"%r.choice([0,0.1])+
