@@ -1016,7 +1016,7 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     const int n_mesh = (int)sc->mesh_prims.size();
     if (w.base && w.slots >= slots && w.depth >= depth && w.n_mesh == n_mesh) return HRT_OK;
     if (w.base) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(w.base); w = WfWorkspace(); }
-    const size_t max_tasks = slots / 256 + 1;
+    const size_t max_tasks = slots / 64 + 1;   // the smallest task HRT_WF_TASK_SIZE can ask for is 64 positions (the default is >= 256)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t f4 = al(slots * sizeof(float4));
     const size_t i4 = al(slots * sizeof(int));

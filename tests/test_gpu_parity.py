@@ -204,6 +204,15 @@ def test_wavefront_sample_chunking_and_paths_agree(teapot, monkeypatch):
         assert np.array_equal(one.view(np.uint32), img.view(np.uint32)), f"tail round {tr}"
         tails.append(st)
     monkeypatch.delenv("HRT_WF_TAIL_ROUND")
+    # nor can the task size (64 .. 4096 positions; the per-task arrays are sized for the smallest one -- a campaign of
+    # tests/tools/gpu_fuzz_launch.py found them sized for the default minimum of 256 and tasks lost with 64)
+    for ts in ("64", "128", "4096"):
+        monkeypatch.setenv("HRT_WF_TASK_SIZE", ts)
+        for tr in ("1", "50"):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tr)
+            img, st = dev.render_tile(cam, api.default_params(W, H, spp, stats=True))
+            assert np.array_equal(one.view(np.uint32), img.view(np.uint32)) and st.rays == s1.rays, f"task size {ts}, tail round {tr}"
+    monkeypatch.delenv("HRT_WF_TASK_SIZE"); monkeypatch.delenv("HRT_WF_TAIL_ROUND")
     # hrt_stats.traversal_*: what the k_wf_ext LAUNCHES tested (the rest: root-filter tests of gen/pre/shade and the tail's rounds)
     assert tails[0].traversal_box_tests == 0 and tails[0].traversal_tri_tests == 0
     assert 0 < tails[1].traversal_box_tests < tails[2].traversal_box_tests < tails[3].traversal_box_tests < s1.box_tests
