@@ -422,6 +422,19 @@ __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4
     r.idx = fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : 1.0f / d.x;
     r.idy = fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : 1.0f / d.y;
     r.idz = fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : 1.0f / d.z;
+    // Nothing in mesh_ray_grid may overflow: inf - inf = NaN in a slab term culls the box.  |1/d| is at most 1e30 here, so
+    // a mesh more than ~1e8 units wide, or seen from that far, met by a ray with a (near-)zero direction component would
+    // (a chain of triangles 7e10 units long lost EVERY hit of the rays parallel to an axis).  Cap the reciprocal on such an
+    // axis so that both terms stay below 1e37: the slab's entry and exit still come out as -/+ 1e32 or more, beyond any real
+    // t, which is all a (near-)parallel ray needs from them.  Never active below those sizes, so nothing else changes.
+    // (idx..idz feed the culling arithmetic only; the wavefront record carries the capped values.)
+    {
+        const float mx = fmaxf(65535.0f * step.x, fabsf(o.x - origin.x)), my = fmaxf(65535.0f * step.y, fabsf(o.y - origin.y)),
+                    mz = fmaxf(65535.0f * step.z, fabsf(o.z - origin.z));
+        if (fabsf(r.idx) * mx > 1e37f) r.idx = copysignf(1e37f / mx, r.idx);
+        if (fabsf(r.idy) * my > 1e37f) r.idy = copysignf(1e37f / my, r.idy);
+        if (fabsf(r.idz) * mz > 1e37f) r.idz = copysignf(1e37f / mz, r.idz);
+    }
     mesh_ray_grid(r, origin, step);
     return r;
 }

@@ -936,13 +936,16 @@ hrt_status validate(const hrt_flat_scene* f) {
     // vertex positions feed the culling-node packer and the traversal's index arithmetic: NaN / inf there is refused, not rendered
     for (uint64_t i = 0; i < (uint64_t)f->n_tris * 9; ++i)
         if (!std::isfinite(f->tri_pos[i])) return fail(HRT_ERR_INVALID, "non-finite vertex position (triangle " + std::to_string(i / 9) + ")");
+    // ... and so is a mesh whose extent could overflow fp32: the culling grid needs 65535 x step finite (hrt_pack.h)
+    for (uint64_t i = 0; i < (uint64_t)f->n_tris * 9; ++i)
+        if (std::fabs(f->tri_pos[i]) > 8e37f) return fail(HRT_ERR_UNSUPPORTED, "vertex coordinate beyond +-8e37 (triangle " + std::to_string(i / 9) + ")");
     for (uint32_t i = 0; i < f->n_nodes; ++i) {
         const hrt_bvh_node& n = f->nodes[i];
         const float b[12] = {n.c0_min_x, n.c0_min_y, n.c0_min_z, n.c0_max_x, n.c0_max_y, n.c0_max_z, n.c1_min_x, n.c1_min_y, n.c1_min_z, n.c1_max_x, n.c1_max_y, n.c1_max_z};
         for (int c = 0; c < 2; ++c) {
             if (b[6 * c] > b[6 * c + 3]) continue;                      // empty child marker (+inf, -inf)
             for (int k = 0; k < 6; ++k)
-                if (!std::isfinite(b[6 * c + k])) return fail(HRT_ERR_INVALID, "non-finite BVH box (node " + std::to_string(i) + ")");
+                if (!std::isfinite(b[6 * c + k]) || std::fabs(b[6 * c + k]) > 8.1e37f) return fail(HRT_ERR_INVALID, "non-finite or out-of-range BVH box (node " + std::to_string(i) + ")");
         }
     }
     return HRT_OK;

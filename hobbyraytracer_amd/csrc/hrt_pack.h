@@ -74,8 +74,8 @@ inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, s
         }
         for (int a = 0; a < 3; ++a) {
             if (lo[a] > hi[a]) { lo[a] = 0.0f; hi[a] = 0.0f; }
-            const float ext = hi[a] - lo[a];
-            float step = ext / 65000.0f;                 // head-room: hi must decode to <= 65535 whatever the rounding
+            float step = hi[a] / 65000.0f - lo[a] / 65000.0f;   // (not (hi - lo) / 65000: the extent itself may exceed FLT_MAX)
+            // 65000, not 65535 -- head-room: hi must decode to <= 65535 whatever the rounding
             if (!(step > 1e-30f)) step = 1e-30f;
             g[a] = lo[a]; g[4 + a] = step;
         }

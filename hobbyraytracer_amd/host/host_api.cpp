@@ -1,6 +1,7 @@
 // host_api.cpp — C ABI of libhrt_host.so (include/hrt_host.h).
 #include <cstring>
 #include <iostream>
+#include <new>
 #include <string>
 
 #include "../../include/hrt_host.h"
@@ -21,6 +22,15 @@ struct hrt_host_scene {
 namespace {
 thread_local std::string g_host_err;
 hrt_status hfail(hrt_status s, const std::string& m) { g_host_err = m; return s; }
+// No C++ exception may cross the C ABI: a reader that runs out of memory on a hostile header (std::bad_alloc,
+// std::length_error) reports it like any other unreadable file.
+template <class F>
+hrt_status guarded(F&& f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return hfail(HRT_ERR_OOM, "out of host memory"); }
+    catch (const std::exception& e) { return hfail(HRT_ERR_INVALID, e.what()); }
+    catch (...) { return hfail(HRT_ERR_INVALID, "unknown C++ exception"); }
+}
 
 // collects BVH depths in flatten order by walking the world again
 void collectDepths(const hrt_flat_scene& f, std::vector<int>& out) {
@@ -62,9 +72,15 @@ hrt_status hrt_host_load_yaml(const char* yaml_path, const char* asset_dir, hrt_
     } catch (const FlattenError& e) {
         delete h;
         return hfail(e.status, e.what());
+    } catch (const std::bad_alloc&) {
+        delete h;
+        return hfail(HRT_ERR_OOM, "out of host memory");
     } catch (const std::exception& e) {
         delete h;
         return hfail(HRT_ERR_INVALID, e.what());
+    } catch (...) {
+        delete h;
+        return hfail(HRT_ERR_INVALID, "unknown C++ exception");
     }
     *out = h;
     return HRT_OK;
@@ -73,23 +89,27 @@ void hrt_host_free(hrt_host_scene* s) { delete s; }
 const hrt_flat_scene* hrt_host_flat(const hrt_host_scene* s) { return s ? &s->flat : nullptr; }
 
 hrt_status hrt_host_film(const hrt_host_scene* s, int32_t* w, int32_t* h, int32_t* samples, char* output, int32_t cap) {
-    if (!s) return hfail(HRT_ERR_INVALID, "NULL scene");
-    film_desc f = s->scene.getFilm()->getFilm();
-    if (w) *w = f.width;
-    if (h) *h = f.height;
-    if (samples) *samples = f.samples;
-    if (output && cap > 0) { std::strncpy(output, s->scene.getFilm()->output().c_str(), (size_t)cap - 1); output[cap - 1] = 0; }
-    return HRT_OK;
+    return guarded([&]() -> hrt_status {
+        if (!s) return hfail(HRT_ERR_INVALID, "NULL scene");
+        film_desc f = s->scene.getFilm()->getFilm();
+        if (w) *w = f.width;
+        if (h) *h = f.height;
+        if (samples) *samples = f.samples;
+        if (output && cap > 0) { std::strncpy(output, s->scene.getFilm()->output().c_str(), (size_t)cap - 1); output[cap - 1] = 0; }
+        return HRT_OK;
+    });
 }
 hrt_status hrt_host_camera(const hrt_host_scene* s, int32_t width, int32_t height, hrt_camera* out) {
-    if (!s || !out || width < 1 || height < 1) return hfail(HRT_ERR_INVALID, "bad argument");
-    // Scene::setFilmSize mutates; work on the const scene through a copy of the descriptor
-    hrt_host_scene* ms = const_cast<hrt_host_scene*>(s);
-    film_desc f = ms->scene.getFilm()->getFilm();
-    ms->scene.setFilmSize(width, height, f.samples);
-    *out = ms->scene.getCamera().flatten();
-    ms->scene.setFilmSize(f.width, f.height, f.samples);
-    return HRT_OK;
+    return guarded([&]() -> hrt_status {
+        if (!s || !out || width < 1 || height < 1) return hfail(HRT_ERR_INVALID, "bad argument");
+        // Scene::setFilmSize mutates; work on the const scene through a copy of the descriptor
+        hrt_host_scene* ms = const_cast<hrt_host_scene*>(s);
+        film_desc f = ms->scene.getFilm()->getFilm();
+        ms->scene.setFilmSize(width, height, f.samples);
+        *out = ms->scene.getCamera().flatten();
+        ms->scene.setFilmSize(f.width, f.height, f.samples);
+        return HRT_OK;
+    });
 }
 int32_t hrt_host_bvh_depth(const hrt_host_scene* s, int32_t mesh) {
     if (!s || mesh < 0 || (size_t)mesh >= s->mesh_depth.size()) return -1;
@@ -106,73 +126,89 @@ void hrt_default_params(hrt_params* p, int32_t width, int32_t height, int32_t sa
     p->seed_lo = 0; p->seed_hi = 0; p->flags = 0;
 }
 
-int64_t hrt_asset_write_teapot_obj(const char* path, double detail) { return path ? writeTeapotObj(path, detail) : -1; }
-int64_t hrt_asset_write_bust_obj(const char* path, double detail) { return path ? writeBustObj(path, detail) : -1; }
+int64_t hrt_asset_write_teapot_obj(const char* path, double detail) { try { return path ? writeTeapotObj(path, detail) : -1; } catch (...) { return -1; } }
+int64_t hrt_asset_write_bust_obj(const char* path, double detail) { try { return path ? writeBustObj(path, detail) : -1; } catch (...) { return -1; } }
 hrt_status hrt_asset_write_hall_hdr(const char* path, int32_t w, int32_t h) {
-    if (!path || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
-    return writeHallHdr(path, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    return guarded([&]() -> hrt_status {
+        if (!path || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
+        return writeHallHdr(path, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    });
 }
 
 hrt_status hrt_host_write_image(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
-    if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
-    Film f(w, h, 1, path);
-    std::memcpy(f.getPixels(), rgb, (size_t)w * h * 3);
-    return f.outputFilm() == 1 ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    return guarded([&]() -> hrt_status {
+        if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
+        Film f(w, h, 1, path);
+        std::memcpy(f.getPixels(), rgb, (size_t)w * h * 3);
+        return f.outputFilm() == 1 ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    });
 }
 hrt_status hrt_host_read_hdr(const char* path, int32_t* w, int32_t* h, float* out, int64_t cap) {
-    if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
-    std::vector<float> d; int ww, hh; std::string err;
-    if (!readHDR(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
-    *w = ww; *h = hh;
-    if (out) {
-        if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
-        std::memcpy(out, d.data(), d.size() * sizeof(float));
-    }
-    return HRT_OK;
+    return guarded([&]() -> hrt_status {
+        if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
+        std::vector<float> d; int ww, hh; std::string err;
+        if (!readHDR(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
+        *w = ww; *h = hh;
+        if (out) {
+            if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
+            std::memcpy(out, d.data(), d.size() * sizeof(float));
+        }
+        return HRT_OK;
+    });
 }
 hrt_status hrt_host_read_png(const char* path, int32_t* w, int32_t* h, uint8_t* out, int64_t cap) {
-    if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
-    std::vector<uint8_t> d; int ww, hh; std::string err;
-    if (!readPNG(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
-    *w = ww; *h = hh;
-    if (out) {
-        if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
-        std::memcpy(out, d.data(), d.size());
-    }
-    return HRT_OK;
+    return guarded([&]() -> hrt_status {
+        if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
+        std::vector<uint8_t> d; int ww, hh; std::string err;
+        if (!readPNG(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
+        *w = ww; *h = hh;
+        if (out) {
+            if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
+            std::memcpy(out, d.data(), d.size());
+        }
+        return HRT_OK;
+    });
 }
 hrt_status hrt_host_write_hdr(const char* path, const float* rgb, int32_t w, int32_t h) {
-    if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
-    return writeHDR(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    return guarded([&]() -> hrt_status {
+        if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
+        return writeHDR(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    });
 }
 
 hrt_status hrt_host_read_jpeg(const char* path, int32_t* w, int32_t* h, uint8_t* out, int64_t cap) {
-    if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
-    std::vector<uint8_t> d;
-    int ww = 0, hh = 0;
-    std::string err;
-    if (!readJPEG(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
-    *w = ww; *h = hh;
-    if (!out) return HRT_OK;
-    if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
-    std::memcpy(out, d.data(), d.size());
-    return HRT_OK;
+    return guarded([&]() -> hrt_status {
+        if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
+        std::vector<uint8_t> d;
+        int ww = 0, hh = 0;
+        std::string err;
+        if (!readJPEG(path, d, ww, hh, err)) return hfail(HRT_ERR_IO, err);
+        *w = ww; *h = hh;
+        if (!out) return HRT_OK;
+        if (cap < (int64_t)d.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
+        std::memcpy(out, d.data(), d.size());
+        return HRT_OK;
+    });
 }
 hrt_status hrt_host_write_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {
-    if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
-    return writePFM(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    return guarded([&]() -> hrt_status {
+        if (!path || !rgb || w < 1 || h < 1) return hfail(HRT_ERR_INVALID, "bad argument");
+        return writePFM(path, rgb, w, h) ? HRT_OK : hfail(HRT_ERR_IO, std::string("cannot write ") + path);
+    });
 }
 hrt_status hrt_host_read_pfm(const char* path, int32_t* w, int32_t* h, float* out, int64_t cap) {
-    if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
-    std::vector<float> rgb;
-    int iw = 0, ih = 0;
-    std::string err;
-    if (!readPFM(path, rgb, iw, ih, err)) return hfail(HRT_ERR_IO, err);
-    *w = iw; *h = ih;
-    if (!out) return HRT_OK;
-    if (cap < (int64_t)rgb.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
-    std::memcpy(out, rgb.data(), rgb.size() * sizeof(float));
-    return HRT_OK;
+    return guarded([&]() -> hrt_status {
+        if (!path || !w || !h) return hfail(HRT_ERR_INVALID, "bad argument");
+        std::vector<float> rgb;
+        int iw = 0, ih = 0;
+        std::string err;
+        if (!readPFM(path, rgb, iw, ih, err)) return hfail(HRT_ERR_IO, err);
+        *w = iw; *h = ih;
+        if (!out) return HRT_OK;
+        if (cap < (int64_t)rgb.size()) return hfail(HRT_ERR_INVALID, "output buffer too small");
+        std::memcpy(out, rgb.data(), rgb.size() * sizeof(float));
+        return HRT_OK;
+    });
 }
 
 }  // extern "C"

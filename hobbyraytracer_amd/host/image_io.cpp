@@ -244,6 +244,9 @@ bool readPNG(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h,
                           (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
                           ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
     if (w <= 0 || h <= 0 || !ch || !depth_ok || interlace > 1) { err = "unsupported PNG (colour type / bit depth / interlace method)"; return false; }
+    // stb_image's limits (the reference's decoder): STBI_MAX_DIMENSIONS = 1 << 24 per side, and width * height * 4 must
+    // fit an int ("too large")
+    if (w > (1 << 24) || h > (1 << 24) || (uint64_t)w * (uint64_t)h > (uint64_t)0x7fffffff / 4) { err = "PNG too large"; return false; }
     if (ctype == 3 && plte.empty()) { err = "palette PNG without PLTE"; return false; }
     // Adam7 passes (or the one pass of a non-interlaced file): origin and spacing of the pass's pixels
     static const int kX0[7] = {0, 4, 0, 2, 0, 1, 0}, kY0[7] = {0, 0, 4, 0, 2, 0, 1}, kDX[7] = {8, 8, 4, 4, 2, 2, 1}, kDY[7] = {8, 8, 8, 4, 4, 2, 2};
@@ -257,6 +260,9 @@ bool readPNG(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h,
         ph[k] = interlace ? (h - kY0[k] + kDY[k] - 1) / kDY[k] : h;
         if (pw[k] > 0 && ph[k] > 0) total += ((size_t)(((size_t)pw[k] * bits_pp + 7) / 8) + 1) * ph[k];
     }
+    // deflate expands at most 1032 : 1, so a header that promises more than the IDAT data can hold is refused before
+    // anything of that size is allocated
+    if (total > idat.size() * 1032 + 1024) { err = "PNG inflate failed"; return false; }
     std::vector<uint8_t> raw(total);
     uLongf rl = (uLongf)raw.size();
     if (uncompress(raw.data(), &rl, idat.data(), (uLong)idat.size()) != Z_OK || rl != raw.size()) { err = "PNG inflate failed"; return false; }

@@ -108,44 +108,57 @@ inline uint8_t clamp8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : (uint8_t)x); 
 
 // One 8-point pass of the integer inverse DCT ("islow"); constants are round(c * 4096).  Inputs s[0..7]; returns the
 // even part in x[0..3] and the odd part in t[0..3], both scaled by 4096, to be combined by the caller.
-inline int fx(double c) { return (int)(c * 4096 + 0.5); }
-inline void idct_1d(const int s[8], int x[4], int t[4]) {
-    int p2 = s[2], p3 = s[6];
-    int p1 = (p2 + p3) * fx(0.5411961);
-    int t2 = p1 + p3 * fx(-1.847759065);
-    int t3 = p1 + p2 * fx(0.765366865);
+// Corrupt files can hold coefficients far outside what an encoder produces; all sums and products below are taken
+// modulo 2^32 (unsigned arithmetic, converted back for the arithmetic shifts), which is what the reference's decoder does
+// in practice on such data, instead of overflowing a signed int.
+struct W {                                        // int with wrapping +, -, *
+    uint32_t u;
+    W() : u(0) {}
+    W(int x) : u((uint32_t)x) {}
+    int i() const { return (int)u; }
+    friend W operator+(W a, W b) { W r; r.u = a.u + b.u; return r; }
+    friend W operator-(W a, W b) { W r; r.u = a.u - b.u; return r; }
+    friend W operator*(W a, W b) { W r; r.u = a.u * b.u; return r; }
+    W& operator+=(W b) { u += b.u; return *this; }
+};
+inline W fx(double c) { return W((int)(c * 4096 + 0.5)); }
+inline void idct_1d(const W s[8], W x[4], W t[4]) {
+    W p2 = s[2], p3 = s[6];
+    W p1 = (p2 + p3) * fx(0.5411961);
+    W t2 = p1 + p3 * fx(-1.847759065);
+    W t3 = p1 + p2 * fx(0.765366865);
     p2 = s[0]; p3 = s[4];
-    int t0 = (p2 + p3) * 4096, t1 = (p2 - p3) * 4096;
+    W t0 = (p2 + p3) * W(4096), t1 = (p2 - p3) * W(4096);
     x[0] = t0 + t3; x[3] = t0 - t3; x[1] = t1 + t2; x[2] = t1 - t2;
     t0 = s[7]; t1 = s[5]; t2 = s[3]; t3 = s[1];
-    p3 = t0 + t2; int p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-    int p5 = (p3 + p4) * fx(1.175875602);
+    p3 = t0 + t2; W p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+    W p5 = (p3 + p4) * fx(1.175875602);
     t0 = t0 * fx(0.298631336); t1 = t1 * fx(2.053119869); t2 = t2 * fx(3.072711026); t3 = t3 * fx(1.501321110);
     p1 = p5 + p1 * fx(-0.899976223); p2 = p5 + p2 * fx(-2.562915447);
     p3 = p3 * fx(-1.961570560); p4 = p4 * fx(-0.390180644);
     t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
 }
 void idct_block(uint8_t* out, int stride, const int16_t d[64]) {
-    int v[64];
+    W v[64];
     for (int c = 0; c < 8; ++c) {                 // columns: keep 2 extra bits
-        int s[8], x[4], t[4];
-        for (int r = 0; r < 8; ++r) s[r] = d[8 * r + c];
+        W s[8], x[4], t[4];
+        for (int r = 0; r < 8; ++r) s[r] = W(d[8 * r + c]);
         idct_1d(s, x, t);
-        for (int k = 0; k < 4; ++k) x[k] += 512;
-        v[0 * 8 + c] = (x[0] + t[3]) >> 10; v[7 * 8 + c] = (x[0] - t[3]) >> 10;
-        v[1 * 8 + c] = (x[1] + t[2]) >> 10; v[6 * 8 + c] = (x[1] - t[2]) >> 10;
-        v[2 * 8 + c] = (x[2] + t[1]) >> 10; v[5 * 8 + c] = (x[2] - t[1]) >> 10;
-        v[3 * 8 + c] = (x[3] + t[0]) >> 10; v[4 * 8 + c] = (x[3] - t[0]) >> 10;
+        for (int k = 0; k < 4; ++k) x[k] += W(512);
+        v[0 * 8 + c] = W((x[0] + t[3]).i() >> 10); v[7 * 8 + c] = W((x[0] - t[3]).i() >> 10);
+        v[1 * 8 + c] = W((x[1] + t[2]).i() >> 10); v[6 * 8 + c] = W((x[1] - t[2]).i() >> 10);
+        v[2 * 8 + c] = W((x[2] + t[1]).i() >> 10); v[5 * 8 + c] = W((x[2] - t[1]).i() >> 10);
+        v[3 * 8 + c] = W((x[3] + t[0]).i() >> 10); v[4 * 8 + c] = W((x[3] - t[0]).i() >> 10);
     }
     for (int r = 0; r < 8; ++r) {                 // rows: remove 2^17, add the level shift
-        int x[4], t[4];
+        W x[4], t[4];
         idct_1d(&v[8 * r], x, t);
-        for (int k = 0; k < 4; ++k) x[k] += 65536 + (128 << 17);
+        for (int k = 0; k < 4; ++k) x[k] += W(65536 + (128 << 17));
         uint8_t* o = out + (size_t)r * stride;
-        o[0] = clamp8((x[0] + t[3]) >> 17); o[7] = clamp8((x[0] - t[3]) >> 17);
-        o[1] = clamp8((x[1] + t[2]) >> 17); o[6] = clamp8((x[1] - t[2]) >> 17);
-        o[2] = clamp8((x[2] + t[1]) >> 17); o[5] = clamp8((x[2] - t[1]) >> 17);
-        o[3] = clamp8((x[3] + t[0]) >> 17); o[4] = clamp8((x[3] - t[0]) >> 17);
+        o[0] = clamp8((x[0] + t[3]).i() >> 17); o[7] = clamp8((x[0] - t[3]).i() >> 17);
+        o[1] = clamp8((x[1] + t[2]).i() >> 17); o[6] = clamp8((x[1] - t[2]).i() >> 17);
+        o[2] = clamp8((x[2] + t[1]).i() >> 17); o[5] = clamp8((x[2] - t[1]).i() >> 17);
+        o[3] = clamp8((x[3] + t[0]).i() >> 17); o[4] = clamp8((x[3] - t[0]).i() >> 17);
     }
 }
 

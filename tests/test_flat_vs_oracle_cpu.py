@@ -153,6 +153,56 @@ def test_mesh_with_a_huge_dynamic_range(built, tmp_path, tools, n):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [30, 60, 100])
+def test_axis_parallel_rays_on_very_wide_meshes(built, tmp_path, tools, n):
+    """Rays with a zero / 1e-35 / 1e-32 direction component against meshes 4e5, 7e10 and 8e17 units wide.  The culling
+    arithmetic works with a clamped reciprocal (1e30 for such components); times a grid step of 1e6 and 65535 cells that
+    overflowed, inf - inf culled the root, and the 7e10 mesh lost EVERY such hit.  hrt_device.h mesh_ray_grid now caps the
+    reciprocal so that no slab term exceeds 1e37."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import chain_scene
+    hs = api.HostScene(chain_scene(tmp_path, n, 1.5), str(tmp_path))
+    world, flat = orc.World(hs.flat_ptr), FlatCpu(hs.flat_ptr)
+    r = np.random.default_rng(3)
+    m = 40000
+    tx = r.uniform(2, 40, m)
+    o = np.stack([tx, r.uniform(-0.5, 0.5, m) * tx / 4, np.full(m, 12.0)], 1).astype(np.float32)
+    d = np.zeros((m, 3), np.float32); d[:, 2] = -1
+    which = r.integers(0, 4, m)
+    d[which == 1, 0] = 1e-35; d[which == 2, 1] = -1e-32; d[which == 3, 0] = r.normal(scale=1e-3, size=(which == 3).sum())
+    p = api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED)
+    g, c = flat.closest_hit(p, o, d), world.closest_hit(p, o, d)
+    assert (c["tri"] >= 0).sum() > 15000
+    assert np.array_equal(g["tri"], c["tri"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+
+
+def test_mesh_as_wide_as_fp32_allows(built, tmp_path, tools):
+    """Vertices at +-8e37, the largest hrt_scene_create accepts (beyond that the extent of the root box could overflow
+    fp32; refused with HRT_ERR_UNSUPPORTED, tests/test_gpu_scenes.py).  Grid step and slab terms stay finite
+    (hrt_pack.h pack_nodes, mesh_ray_setup); film and counters as the oracle."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    (tmp_path / "t.obj").write_text("vn 0 0 1\nv -8e37 -8e37 0\nv 8e37 -8e37 0\nv 8e37 8e37 0\nv -1 -1 0\nv 1 -1 0\nv 0 1 0\nv 5e37 0 3e37\n"
+                                    "f 1//1 2//1 3//1\nf 4//1 5//1 6//1\nf 4//1 5//1 7//1\n")
+    (tmp_path / "s.yaml").write_text(
+        "film:\n    width: 16\n    height: 16\n    samples: 2\n    output: o.png\n"
+        "camera:\n    position: [0, 0, 3]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 50\n    aperture: 0\n    focal_distance: 3\n"
+        "    background: [0.4, 0.5, 0.6]\n"
+        "materials:\n  - name: m\n    type: lambertian\n    albedo: [0.8, 0.3, 0.3]\n"
+        "objects:\n  - type: mesh\n    path: t.obj\n    material: m\n")
+    hs = api.HostScene(str(tmp_path / "s.yaml"), str(tmp_path))
+    flat = FlatCpu(hs.flat_ptr)
+    qn, gr = flat.packed_nodes()
+    assert np.isfinite(gr).all()
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(16, 16, 2, quirks=q, stats=True)
+        a, sa = flat.render_tile(hs.camera(16, 16), p)
+        b, sb = orc.World(hs.flat_ptr).render_tile(hs.camera(16, 16), p)
+        assert sb.mesh_hits > 1000 and (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_ray_origins_far_from_the_mesh(built, assets, scenes_dir, tools):
     """Rays that start 10 .. 1e6 units from a 3-unit mesh.  fp32 leaves t good to 1e-7 x that distance, so (1) the
     culling arithmetic must allow for its own rounding (hrt_device.h mesh_ray_grid `slack`: without it 4 of 57 k hits were

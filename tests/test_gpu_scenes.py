@@ -150,6 +150,10 @@ def test_scene_validation_refuses_malformed_input(built, assets, scenes_dir):
     with pytest.raises(api.HrtError) as e:
         api.DeviceScene(flat, 0)
     assert e.value.status == api.HRT_ERR_INVALID and "non-finite vertex position (triangle 100)" in str(e.value)
+    pos[9 * 100 + 4] = 1e38                                                                                    # finite, but the mesh extent could overflow fp32
+    with pytest.raises(api.HrtError) as e:
+        api.DeviceScene(flat, 0)
+    assert e.value.status == api.HRT_ERR_UNSUPPORTED and "beyond +-8e37 (triangle 100)" in str(e.value)
 
 
 def test_device_pointer_stream_api_with_torch(built, assets, scenes_dir):
