@@ -777,8 +777,8 @@ __device__ inline vec3 tex_leaf(const DScene& sc, const hrt_texture& t, float u,
     if (t.kind == HRT_TEX_IMAGE) {  // texture.cpp:53-74
         u = gclamp(u, 0.0f, 1.0f);
         v = 1.0f - gclamp(v, 0.0f, 1.0f);
-        int i = static_cast<int>(u * t.width);
-        int j = static_cast<int>(v * t.height);
+        int i = texel_index(u * t.width);
+        int j = texel_index(v * t.height);
         if (i >= t.width) i = t.width - 1;
         if (j >= t.height) j = t.height - 1;
         const float colourScale = 1.0f / 255.0f;
@@ -788,8 +788,8 @@ __device__ inline vec3 tex_leaf(const DScene& sc, const hrt_texture& t, float u,
     // HRT_TEX_ENV: texture.cpp:76-97
     u = gclamp(u, 0.0f, 1.0f);
     v = gclamp(v, 0.0f, 1.0f);
-    int i = static_cast<int>((u * (t.width - 1)) + 0.5f);
-    int j = static_cast<int>((v * (t.height - 1)) + 0.5f);
+    int i = texel_index((u * (t.width - 1)) + 0.5f);
+    int j = texel_index((v * (t.height - 1)) + 0.5f);
     const float* px = sc.texels_f32 + t.offset + ((size_t)j * t.width + i) * t.channels;
     return vec3(px[0], px[1], px[2]);
 }

@@ -45,6 +45,13 @@ namespace hrt {
 HRT_HD float gmin(float x, float y) { return (y < x) ? y : x; }
 HRT_HD float gmax(float x, float y) { return (x < y) ? y : x; }
 HRT_HD float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+// float -> texel index.  glm::clamp lets NaN through ((NaN < lo) and (hi < NaN) are both false), and the reference then
+// converts NaN to int -- undefined behaviour (x86: INT_MIN and a wild read; gfx950's v_cvt_i32_f32: 0).  NaN texture
+// coordinates do occur (a path that went NaN under quirk Q-4 looks the background up with a NaN direction), so the
+// conversion is pinned to the GPU's answer, 0, on every build.
+// (fmaxf returns its non-NaN operand; the arguments here are never negative, so nothing else changes.  One v_max_f32 --
+// the obvious `x == x ? (int)x : 0` made hipcc spill 592 bytes per lane in k_wf_shade and cost 36 ms per frame.)
+HRT_HD int texel_index(float x) { return static_cast<int>(fmaxf(x, 0.0f)); }
 HRT_HD double gmind(double x, double y) { return (y < x) ? y : x; }
 
 HRT_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

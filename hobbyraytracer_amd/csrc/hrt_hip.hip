@@ -866,13 +866,19 @@ hrt_status validate(const hrt_flat_scene* f) {
             if (t.even < 0 || (uint32_t)t.even >= f->n_textures || t.odd < 0 || (uint32_t)t.odd >= f->n_textures)
                 return fail(HRT_ERR_INVALID, "checker child out of range");
         }
-        if (t.kind == HRT_TEX_IMAGE && t.width > 0) {
-            if (t.height <= 0) return fail(HRT_ERR_INVALID, "image texture height");
-            if (t.offset + (uint64_t)t.width * t.height * 3 > f->n_texels_u8) return fail(HRT_ERR_INVALID, "image texels out of range");
-        }
-        if (t.kind == HRT_TEX_ENV && t.width > 0) {
-            if (t.height <= 0 || t.channels < 3) return fail(HRT_ERR_INVALID, "environment map needs >= 3 channels");
-            if (t.offset + (uint64_t)t.width * t.height * t.channels > f->n_texels_f32) return fail(HRT_ERR_INVALID, "env texels out of range");
+        // width == 0 or height == 0 is the reference's "image failed to load" texture (texture.cpp:56-57, 79-80: cyan); any
+        // other size must be positive and lie inside its texel array (the sums below cannot wrap: w, h < 2^31, channels < 2^31)
+        if (t.kind == HRT_TEX_IMAGE || t.kind == HRT_TEX_ENV) {
+            if (t.width < 0 || t.height < 0) return fail(HRT_ERR_INVALID, "negative texture size");
+            if (t.width > 0 && t.height > 0) {
+                const bool env = t.kind == HRT_TEX_ENV;
+                if (env && t.channels < 3) return fail(HRT_ERR_INVALID, "environment map needs >= 3 channels");
+                const uint64_t have = env ? f->n_texels_f32 : f->n_texels_u8;
+                const uint64_t per = (uint64_t)t.width * (uint64_t)t.height;          // < 2^62
+                const uint64_t ch = env ? (uint64_t)t.channels : 3u;
+                if (t.offset > have || per > (have - t.offset) / ch) return fail(HRT_ERR_INVALID, env ? "env texels out of range" : "image texels out of range");
+                if (have && !(env ? (const void*)f->texels_f32 : (const void*)f->texels_u8)) return fail(HRT_ERR_INVALID, "texel array is NULL");
+            }
         }
     }
     auto tex_ok = [&](int32_t t) { return t < 0 || (uint32_t)t < f->n_textures; };
@@ -973,6 +979,9 @@ hrt_status check_params(const hrt_params* p) {
     if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HRT_ERR_UNSUPPORTED, "film larger than 2^30 pixels");
     if (p->samples < 1) return fail(HRT_ERR_INVALID, "samples must be >= 1");
     if (p->max_depth < 1) return fail(HRT_ERR_INVALID, "max_depth must be >= 1");
+    // the wavefront pipeline enqueues two launches and 3 KB of counters per round whether paths are left or not
+    if (p->max_depth > 65536) return fail(HRT_ERR_UNSUPPORTED, "max_depth above 65536 (the reference's is 50, main.cpp:32)");
+    if (!(p->t_min == p->t_min)) return fail(HRT_ERR_INVALID, "t_min is NaN");
     return HRT_OK;
 }
 

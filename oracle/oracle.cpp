@@ -134,8 +134,8 @@ struct ImageTexture : Texture {  // texture.cpp:53-74
         if (width == 0 || height == 0) return vec3(0, 1, 1);
         u = gclamp(u, 0.0f, 1.0f);
         v = 1.0f - gclamp(v, 0.0f, 1.0f);
-        int i = static_cast<int>(u * width);
-        int j = static_cast<int>(v * height);
+        int i = texel_index(u * width);
+        int j = texel_index(v * height);
         if (i >= width) i = width - 1;
         if (j >= height) j = height - 1;
         const float colourScale = 1.0f / 255.0f;
@@ -151,8 +151,8 @@ struct EnvironmentMap : Texture {  // texture.cpp:76-97
         if (width == 0 || height == 0) return vec3(0, 1, 1);
         u = gclamp(u, 0.0f, 1.0f);
         v = gclamp(v, 0.0f, 1.0f);
-        int i = static_cast<int>((u * (width - 1)) + 0.5f);
-        int j = static_cast<int>((v * (height - 1)) + 0.5f);
+        int i = texel_index((u * (width - 1)) + 0.5f);
+        int j = texel_index((v * (height - 1)) + 0.5f);
         size_t b = ((size_t)j * width + i) * channels;
         return vec3(data[b], data[b + 1], data[b + 2]);
     }

@@ -87,6 +87,44 @@ def test_status_strings_and_stripe_partition_need_no_gpu(built):
         assert sorted(seen) == list(range(H))
 
 
+def test_scene_validation_runs_before_any_device_is_touched(built, tmp_path):
+    """hrt_scene_create validates the flat scene first, so malformed input is refused with HRT_ERR_INVALID / UNSUPPORTED on
+    a box without a GPU too (a valid scene gets HRT_ERR_NO_DEVICE there, HRT_OK on a GPU box).  Cases found by
+    tests/tools/fuzz_flat.py: a negative texture width passed (only width > 0 was checked) and indexed in front of the texel
+    array; offset + size could wrap around 2^64."""
+    import ctypes as C
+    from hobbyraytracer_amd import api
+    api.write_hall_hdr(str(tmp_path / "old_hall_4k.hdr"), 32, 16)
+    api.write_teapot_obj(str(tmp_path / "teapot.obj"), 0.05)
+    hs = api.HostScene(os.path.join(os.path.dirname(__file__), "golden", "scenes", "teapot_scene.yaml"), str(tmp_path))
+
+    def create(flat):
+        h = C.c_void_p()
+        st = api._hip.hrt_scene_create(C.byref(flat), 0, C.byref(h))
+        if st == api.HRT_OK:
+            api._hip.hrt_scene_destroy(h)
+        return st, api._hip.hrt_last_error().decode()
+
+    def with_texture(edit):
+        flat = api.FlatScene()
+        C.memmove(C.byref(flat), hs.flat_ptr, C.sizeof(api.FlatScene))
+        texs = (api.Texture * flat.n_textures)()
+        C.memmove(texs, flat.textures, C.sizeof(texs))
+        env = [i for i in range(flat.n_textures) if texs[i].kind == api.TEX_ENV][0]
+        edit(texs[env])
+        flat.textures = C.cast(texs, C.POINTER(api.Texture))
+        return create(flat) + (texs,)
+
+    assert create(hs.flat)[0] in (api.HRT_OK, api.HRT_ERR_NO_DEVICE)
+    for edit, what in ((lambda t: setattr(t, "width", -1), "negative texture size"), (lambda t: setattr(t, "height", -7), "negative texture size"),
+                       (lambda t: setattr(t, "offset", 2**64 - 8), "env texels out of range"), (lambda t: setattr(t, "width", 2**31 - 1), "env texels out of range"),
+                       (lambda t: setattr(t, "channels", 2), "environment map needs >= 3 channels"), (lambda t: setattr(t, "channels", 2**31 - 1), "env texels out of range")):
+        st, msg, _ = with_texture(edit)
+        assert st == api.HRT_ERR_INVALID and what in msg, (st, msg)
+    st, msg, _ = with_texture(lambda t: setattr(t, "width", 0))        # the reference's "failed to load" texture: allowed (cyan)
+    assert st in (api.HRT_OK, api.HRT_ERR_NO_DEVICE), msg
+
+
 def test_cli_binary_exists_and_reports_load_failure(built, tmp_path):
     from hobbyraytracer_amd import api
     assert os.access(api.CLI_PATH, os.X_OK)

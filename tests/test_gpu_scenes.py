@@ -142,6 +142,17 @@ def test_scene_validation_refuses_malformed_input(built, assets, scenes_dir):
         api.DeviceScene(hs.flat_ptr, 0).render_tile(hs.camera(8, 8), api.default_params(8, 8, 1), (4, 4, 8, 8))   # tile outside the film
     with pytest.raises(api.HrtError):
         api.DeviceScene(hs.flat_ptr, 77)                                                                       # no such device
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    for bad in (dict(max_depth=0), dict(max_depth=10**6)):                                                     # rounds: 1 .. 65536
+        with pytest.raises(api.HrtError):
+            dev.render_tile(hs.camera(8, 8), api.default_params(8, 8, 1, **bad))
+    nan_tmin = api.default_params(8, 8, 1); nan_tmin.t_min = float("nan")
+    zero_spp = api.default_params(8, 8, 1); zero_spp.samples = 0
+    tiny = api.default_params(8, 8, 1); tiny.width = 1
+    for p in (nan_tmin, zero_spp, tiny):
+        with pytest.raises(api.HrtError):
+            dev.render_tile(hs.camera(8, 8), p)
+    dev.close()
     C.memmove(C.byref(flat), hs.flat_ptr, C.sizeof(api.FlatScene))
     pos = (C.c_float * (flat.n_tris * 9))()
     C.memmove(pos, flat.tri_pos, C.sizeof(pos))
