@@ -361,24 +361,26 @@ __device__ inline bool tri_eval(const TriRay& tr, vec3 v0, vec3 v1, vec3 v2, Tri
 }
 // The leaf-level BVHNode::hit box test of the reference tree (aabb.h:26-39 on
 // the box of bvh.cpp:52-60), evaluated only for candidates that passed the
-// triangle test.
+// triangle test.  std::min(a, b) is (b < a) ? b : a and std::max(a, b) is (a < b) ? b : a -- the ARGUMENT ORDER of
+// aabb.h:29-34 is kept, because it decides what a NaN does: a NaN t_max (the hit so far came from a degenerate primitive)
+// is replaced by the slab's own exit, a NaN slab (NaN ray) replaces t_min and t_max and the box passes.
 __device__ inline bool accept_box(float4 bmn, float4 bmx, vec3 o, vec3 d, float t_min, float t_max) {
     {
         float ta = (bmn.x - o.x) / d.x, tb = (bmx.x - o.x) / d.x;
         float t0 = (tb < ta) ? tb : ta; float t1 = (ta < tb) ? tb : ta;
-        t_min = (t_min < t0) ? t0 : t_min; t_max = (t1 < t_max) ? t1 : t_max;
+        t_min = (t0 < t_min) ? t_min : t0; t_max = (t_max < t1) ? t_max : t1;   // std::max(t0, t_min), std::min(t1, t_max)
         if (t_max <= t_min) return false;
     }
     {
         float ta = (bmn.y - o.y) / d.y, tb = (bmx.y - o.y) / d.y;
         float t0 = (tb < ta) ? tb : ta; float t1 = (ta < tb) ? tb : ta;
-        t_min = (t_min < t0) ? t0 : t_min; t_max = (t1 < t_max) ? t1 : t_max;
+        t_min = (t0 < t_min) ? t_min : t0; t_max = (t_max < t1) ? t_max : t1;   // std::max(t0, t_min), std::min(t1, t_max)
         if (t_max <= t_min) return false;
     }
     {
         float ta = (bmn.z - o.z) / d.z, tb = (bmx.z - o.z) / d.z;
         float t0 = (tb < ta) ? tb : ta; float t1 = (ta < tb) ? tb : ta;
-        t_min = (t_min < t0) ? t0 : t_min; t_max = (t1 < t_max) ? t1 : t_max;
+        t_min = (t0 < t_min) ? t_min : t0; t_max = (t_max < t1) ? t_max : t1;   // std::max(t0, t_min), std::min(t1, t_max)
         if (t_max <= t_min) return false;
     }
     return true;
@@ -456,6 +458,12 @@ struct TravState {
     int sp;
     int cur;              // node index (>= 0), leaf code (< 0) or HRT_TRAV_DONE
 };
+// t_max as a mesh sees it.  A NaN t_max (the hit so far came from a degenerate primitive: Triangle::hit with two equal
+// vertices "hits" every ray with t = NaN) acts like +inf in the reference: aabb.h:34 std::min(t1, NaN) yields t1, and
+// triangle.cpp:106-109 compare against NaN * det, which rejects nothing -- exactly what +inf does.  The culling arithmetic
+// would otherwise drop a NaN RAY at the root (every slab NaN, exit = fmin(NaN, NaN)), where the reference lets it through
+// every box and has the mesh "hit" it.
+__device__ inline float mesh_t_max(float t_max) { return t_max == t_max ? t_max : __builtin_huge_valf(); }
 template <class M>
 __device__ inline void trav_init(TravState& ts, const M& mesh, float t_max) {
     ts.closest = t_max; ts.best = -1;
@@ -635,7 +643,7 @@ __device__ inline int bvh_traverse(const DScene& sc, int mi /* mesh index */, ve
     const MeshRay r = mesh_ray_setup(o, d, quirks, grid_o, grid_s);
     const float t_lo = trav_t_lo(t_min, quirks);
     TravState ts;
-    trav_init(ts, mesh, t_max);
+    trav_init(ts, mesh, mesh_t_max(t_max));
     // while-while: lanes that reach a leaf wait at the end of the inner loop, so the (expensive) leaf code
     // runs with many lanes at once instead of once per node step for the few lanes that happen to be at a leaf
     while (ts.cur != HRT_TRAV_DONE) {

@@ -340,7 +340,7 @@ __device__ inline bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0
     float4 grid_o, grid_s;
     mesh_grid(sc, mp.mesh, grid_o, grid_s);
     mr = mesh_ray_setup(lo, ld, pr.quirks, grid_o, grid_s);
-    const bool enq = root_may_hit(sc, mesh, mr, trav_t_lo(pr.t_min, pr.quirks), closest);
+    const bool enq = root_may_hit(sc, mesh, mr, trav_t_lo(pr.t_min, pr.quirks), mesh_t_max(closest));
     if (STATS && !enq && mesh.node_count) n_culled++;
     return enq;
 }
@@ -499,7 +499,7 @@ __device__ inline void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int m
                     r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
                     mesh_ray_grid(r, em.grid_o, em.grid_s);
                     pos = __float_as_uint(e1.w);
-                    ts.closest = e0.w; ts.best = -1;
+                    ts.closest = mesh_t_max(e0.w); ts.best = -1;
                     ts.selfhit = false; ts.self_order = 0xffffffffu; ts.self_tri = -1; ts.self_t = 0.0f;
                     ts.sp = 0;
                     ts.cur = em.node_count == 0 ? HRT_TRAV_DONE : 0;

@@ -200,3 +200,32 @@ def wrapper_chain_scene(tmp_path, chain):
         "  - type: mesh\n    path: quad.obj\n    material: b\n" + ("    transform:\n" + "".join(xf[c] for c in chain if c != "T") + "        translate: [2, -1, 0]\n") +
         "  - type: xz_rect\n    x: [-6, 6]\n    z: [-6, 6]\n    k: -2.2\n    material: a\n")
     return str(tmp_path / "chain.yaml")
+
+
+def films_equal(a, b):
+    """Bit equality of two linear films, with NaN == NaN: a NaN pixel (a path that met a degenerate primitive) may carry any
+    payload or sign, and Film::tonemap (film.cpp:35-37) scrubs every NaN to 0 before anything is shown."""
+    import numpy as np
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def nan_ray_scene(tmp_path):
+    """A free triangle with two equal vertices, listed BEFORE a mesh and a light.  Triangle::hit (triangle.cpp:4-40)
+    normalises a zero edge: every comparison on the NaNs is false and the triangle "hits" every ray with t = NaN, so the
+    objects after it are asked with t_max = NaN, and the path goes on from a NaN point: the NaN ray passes every box of the
+    reference's tree (aabb.h:29-35 on NaN) and is "hit" by the mesh again."""
+    with open(tmp_path / "quad.obj", "w") as f:
+        f.write("v -1 -1 0\nv 1 -1 0\nv 1 1 0.3\nv -1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n")
+    (tmp_path / "nan.yaml").write_text(
+        "film:\n    width: 32\n    height: 32\n    samples: 4\n    output: o.png\n"
+        "camera:\n    position: [0.3, 0.8, 6]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: 0\n"
+        "    focal_distance: 6\n    background: [0.6, 0.7, 0.9]\n"
+        "materials:\n  - name: a\n    type: lambertian\n    albedo: [0.8, 0.4, 0.3]\n  - name: lamp\n    type: diffuse_light\n"
+        "    albedo: [1, 0.9, 0.8]\n    strength: 3\n  - name: b\n    type: metal\n    albedo: [0.8, 0.8, 0.7]\n    roughness: 0.1\n"
+        "objects:\n"
+        "  - type: sphere\n    center: [-1.5, 0, 0]\n    radius: 0.6\n    material: b\n"
+        "  - type: triangle\n    v0: [1.5, 0.5, 1.5]\n    v1: [1.5, 0.5, 1.5]\n    v2: [1, 2, -0.5]\n    material: a\n"
+        "  - type: mesh\n    path: quad.obj\n    material: lamp\n    transform:\n        rotate_y: 30\n"
+        "  - type: xz_rect\n    x: [-4, 4]\n    z: [-4, 4]\n    k: -1.2\n    material: a\n"
+        "  - type: mesh\n    path: quad.obj\n    material: b\n    transform:\n        translate: [0, 0, -2]\n")
+    return str(tmp_path / "nan.yaml")

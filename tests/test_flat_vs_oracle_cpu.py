@@ -298,6 +298,24 @@ def test_random_worlds(built, tmp_path, tools, extreme, meshes):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, q)
 
 
+def test_nan_rays_and_nan_t_max_from_a_degenerate_triangle(built, tmp_path, tools):
+    """tests/scene_helpers.py nan_ray_scene.  Found by tests/tools/gpu_fuzz.py: the culling arithmetic dropped a NaN ray at
+    a mesh's root when t_max was NaN too (hrt_device.h mesh_t_max), and accept_box had std::min / std::max's arguments
+    the other way round, which only shows with a NaN t_max (aabb.h:33-34).  Film (NaN == NaN) and segment counts as the
+    oracle's; the light is only reached through such paths, so the film is not simply black."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import nan_ray_scene, films_equal
+    hs = api.HostScene(nan_ray_scene(tmp_path), str(tmp_path))
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(32, 32, 4, quirks=q, stats=True)
+        a, sa = FlatCpu(hs.flat_ptr).render_tile(hs.camera(32, 32), p)
+        b, sb = orc.World(hs.flat_ptr).render_tile(hs.camera(32, 32), p)
+        assert (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits) and sb.mesh_hits > 1000
+        assert films_equal(a, b)
+        assert np.isnan(b).any() or (b > 1.0).any()
+
+
 def test_degenerate_meshes(built, tmp_path, tools):
     """Single triangle (root leaf) and the two-triangle case: flattened result == oracle."""
     orc, FlatCpu = tools

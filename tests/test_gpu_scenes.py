@@ -356,6 +356,26 @@ def test_wrapper_chains_of_every_length(built, tmp_path, monkeypatch, chain):
     dev.close()
 
 
+def test_nan_rays_and_nan_t_max_from_a_degenerate_triangle(built, tmp_path, monkeypatch):
+    """The GPU twin of the CPU test of the same name (tests/scene_helpers.py nan_ray_scene): a primitive that "hits" every ray
+    with t = NaN in front of two meshes, on all three render paths."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import nan_ray_scene, films_equal
+    hs = api.HostScene(nan_ray_scene(tmp_path), str(tmp_path))
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    cam = hs.camera(32, 32)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(32, 32, 4, quirks=q, stats=True))
+        assert sr.mesh_hits > 1000
+        for tail, mega in (("1", False), ("1000", False), ("1", True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(32, 32, 4, quirks=q, stats=True, megakernel=mega))
+            assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits), (q, tail, mega)
+            assert films_equal(img, ref), (q, tail, mega)
+    dev.close()
+
+
 def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
     (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
