@@ -345,7 +345,7 @@ __device__ inline bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0
     return enq;
 }
 __device__ inline void wf_store_record(const WfBuf& w, unsigned q, const MeshRay& mr, float closest, unsigned pos) {
-    w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, closest);
+    w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, mesh_t_max(closest));   // what the traversal starts from: NaN -> +inf
     w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pos));
     w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
     w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, 0.0f);
@@ -499,7 +499,7 @@ __device__ inline void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int m
                     r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
                     mesh_ray_grid(r, em.grid_o, em.grid_s);
                     pos = __float_as_uint(e1.w);
-                    ts.closest = mesh_t_max(e0.w); ts.best = -1;
+                    ts.closest = e0.w; ts.best = -1;        // (wf_store_record wrote mesh_t_max(closest))
                     ts.selfhit = false; ts.self_order = 0xffffffffu; ts.self_tri = -1; ts.self_t = 0.0f;
                     ts.sp = 0;
                     ts.cur = em.node_count == 0 ? HRT_TRAV_DONE : 0;
@@ -1219,6 +1219,13 @@ hrt_status fold_pending(hrt_scene* sc) {
 
 }  // namespace
 
+// No C++ exception may cross the C ABI (std::bad_alloc from the packers' vectors, std::length_error ...).
+#define HRT_API_TRY try {
+#define HRT_API_CATCH \
+    } catch (const std::bad_alloc&) { return fail(HRT_ERR_OOM, "out of host memory"); } \
+    catch (const std::exception& e) { return fail(HRT_ERR_INVALID, e.what()); } \
+    catch (...) { return fail(HRT_ERR_INVALID, "unknown C++ exception"); }
+
 extern "C" {
 
 const char* hrt_status_str(hrt_status s) {
@@ -1238,12 +1245,14 @@ const char* hrt_last_error(void) { return g_err.c_str(); }
 const char* hrt_version(void) { return "hrt-mi355x 0.1 (gfx950)"; }
 
 hrt_status hrt_device_count(int* n) {
+    HRT_API_TRY
     if (!n) return fail(HRT_ERR_INVALID, "n is NULL");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     if (e != hipSuccess) { *n = 0; return fail_hip(e, "hipGetDeviceCount"); }
     *n = c;
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 void hrt_scene_destroy(hrt_scene* sc) {
@@ -1258,6 +1267,7 @@ void hrt_scene_destroy(hrt_scene* sc) {
 }
 
 hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out) {
+    HRT_API_TRY
     if (!out) return fail(HRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     hrt_status st = validate(f);
@@ -1324,6 +1334,7 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
         }
     *out = sc;
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 int32_t hrt_stripe_rows(int32_t height, int32_t R, int32_t rank, int32_t G) {
@@ -1344,6 +1355,7 @@ int32_t hrt_stripe_row_index(int32_t height, int32_t R, int32_t rank, int32_t G,
 
 hrt_status hrt_render_stripes_device(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank,
                                      int32_t G, float* d_out, void* stream) {
+    HRT_API_TRY
     if (!sc || !cam || !d_out) return fail(HRT_ERR_INVALID, "NULL argument");
     hrt_status st = check_params(pr);
     if (st != HRT_OK) return st;
@@ -1356,10 +1368,12 @@ hrt_status hrt_render_stripes_device(hrt_scene* sc, const hrt_camera* cam, const
     map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
     map.m_rw = fastdiv_magic((uint32_t)map.rw); map.m_nl = fastdiv_magic((uint32_t)map.rw * (uint32_t)map.rh);
     return launch_pathtrace(sc, cam, pr, map, d_out, (hipStream_t)stream);
+    HRT_API_CATCH
 }
 
 hrt_status hrt_render_stripes_accumulate_device(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank,
                                                 int32_t G, float* d_accum, int32_t sample_first, int32_t sample_count, void* stream) {
+    HRT_API_TRY
     if (!sc || !cam || !d_accum) return fail(HRT_ERR_INVALID, "NULL argument");
     hrt_status st = check_params(pr);
     if (st != HRT_OK) return st;
@@ -1372,10 +1386,12 @@ hrt_status hrt_render_stripes_accumulate_device(hrt_scene* sc, const hrt_camera*
     map.total_items = map.tiles_x * ((map.rh + 7) / 8) * 64;
     map.m_rw = fastdiv_magic((uint32_t)map.rw); map.m_nl = fastdiv_magic((uint32_t)map.rw * (uint32_t)map.rh);
     return launch_pathtrace(sc, cam, pr, map, d_accum, (hipStream_t)stream, sample_first, sample_count);
+    HRT_API_CATCH
 }
 
 hrt_status hrt_render_stripes_accumulate(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank, int32_t G,
                                          float* accum, int32_t sample_first, int32_t sample_count, hrt_stats* stats) {
+    HRT_API_TRY
     if (!sc || !cam || !accum) return fail(HRT_ERR_INVALID, "NULL argument");
     hrt_status st = check_params(pr);
     if (st != HRT_OK) return st;
@@ -1406,9 +1422,11 @@ hrt_status hrt_render_stripes_accumulate(hrt_scene* sc, const hrt_camera* cam, c
     if (st != HRT_OK) return st;
     if (stats) *stats = now;
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
+    HRT_API_TRY
     if (!sc || !stats) return fail(HRT_ERR_INVALID, "NULL argument");
     HIPCHK(hipSetDevice(sc->device));
     HIPCHK(hipDeviceSynchronize());
@@ -1424,10 +1442,12 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     stats->traversal_ms = sc->traversal_ms; stats->traversal_launches = sc->traversal_launches;
     sc->kernel_ms = 0.0; sc->launches = 0; sc->traversal_ms = 0.0; sc->traversal_launches = 0;
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_render_tile(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, hrt_rect tile, float* out,
                            hrt_stats* stats) {
+    HRT_API_TRY
     if (!sc || !cam || !out) return fail(HRT_ERR_INVALID, "NULL argument");
     hrt_status st = check_params(pr);
     if (st != HRT_OK) return st;
@@ -1459,10 +1479,12 @@ hrt_status hrt_render_tile(hrt_scene* sc, const hrt_camera* cam, const hrt_param
     if (st != HRT_OK) return st;
     if (stats) *stats = now;
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_render_stripes(hrt_scene* sc, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t rank, int32_t G,
                               float* out, hrt_stats* stats) {
+    HRT_API_TRY
     if (!sc || !cam || !out) return fail(HRT_ERR_INVALID, "NULL argument");
     hrt_status st = check_params(pr);
     if (st != HRT_OK) return st;
@@ -1490,9 +1512,11 @@ hrt_status hrt_render_stripes(hrt_scene* sc, const hrt_camera* cam, const hrt_pa
     if (st != HRT_OK) return st;
     if (stats) *stats = now;
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_resolve_u8_device(hrt_scene* sc, const float* d_rgb, int64_t n_pixels, uint8_t* d_out, void* stream) {
+    HRT_API_TRY
     if (!sc || !d_rgb || !d_out || n_pixels < 0) return fail(HRT_ERR_INVALID, "bad argument");
     if (n_pixels == 0) return HRT_OK;
     HIPCHK(hipSetDevice(sc->device));
@@ -1501,9 +1525,11 @@ hrt_status hrt_resolve_u8_device(hrt_scene* sc, const float* d_rgb, int64_t n_pi
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_rgb, (long long)n_pixels, d_out);
     HIPCHK(hipGetLastError());
     return HRT_OK;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_resolve_u8(hrt_scene* sc, const float* rgb, int64_t n_pixels, uint8_t* out) {
+    HRT_API_TRY
     if (!sc || !rgb || !out || n_pixels < 0) return fail(HRT_ERR_INVALID, "bad argument");
     if (n_pixels == 0) return HRT_OK;
     HIPCHK(hipSetDevice(sc->device));
@@ -1518,10 +1544,12 @@ hrt_status hrt_resolve_u8(hrt_scene* sc, const float* rgb, int64_t n_pixels, uin
     if (st == HRT_OK) { e = hipMemcpy(out, d_out, (size_t)n_pixels * 3, hipMemcpyDeviceToHost); if (e != hipSuccess) st = fail_hip(e, "hipMemcpy D2H"); }
     (void)hipFree(d_in); (void)hipFree(d_out);
     return st;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_closest_hit(hrt_scene* sc, const hrt_params* pr, int64_t n, const float* o, const float* d, float t_min,
                            float t_max, uint32_t pixel0, hrt_hit* out) {
+    HRT_API_TRY
     if (!sc || !pr || !o || !d || !out || n < 0) return fail(HRT_ERR_INVALID, "bad argument");
     if (n == 0) return HRT_OK;
     HIPCHK(hipSetDevice(sc->device));
@@ -1541,9 +1569,11 @@ hrt_status hrt_closest_hit(hrt_scene* sc, const hrt_params* pr, int64_t n, const
     if (st == HRT_OK && (e = hipMemcpy(out, d_h, (size_t)n * sizeof(hrt_hit), hipMemcpyDeviceToHost)) != hipSuccess) st = fail_hip(e, "hipMemcpy D2H");
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h);
     return st;
+    HRT_API_CATCH
 }
 
 hrt_status hrt_math_probe(int device, int32_t op, int64_t n, const float* in, const float* in2, float* out) {
+    HRT_API_TRY
     if (!in || !out || n < 0 || op < 0 || op > 5) return fail(HRT_ERR_INVALID, "bad argument");
     if ((op == 3 || op == 5) && !in2) return fail(HRT_ERR_INVALID, "in2 required");
     if (n == 0) return HRT_OK;
@@ -1563,6 +1593,7 @@ hrt_status hrt_math_probe(int device, int32_t op, int64_t n, const float* in, co
     if (st == HRT_OK && (e = hipMemcpy(out, d_out, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) st = fail_hip(e, "hipMemcpy D2H");
     (void)hipFree(d_in); (void)hipFree(d_in2); (void)hipFree(d_out);
     return st;
+    HRT_API_CATCH
 }
 
 }  // extern "C"
