@@ -41,7 +41,11 @@ def gather_film(tile, layout, dist=None, out=None, gathered=None):
         src = gathered
     else:
         src = tile
-    perm = torch.as_tensor(layout.perm, device=tile.device)
+    key = str(tile.device)
+    cache = layout.__dict__.setdefault("_perm_on", {})
+    perm = cache.get(key)
+    if perm is None:                                   # uploaded once per device, not once per frame
+        perm = cache[key] = torch.as_tensor(layout.perm, device=tile.device)
     if out is None:
         return torch.index_select(src, 0, perm)
     torch.index_select(src, 0, perm, out=out)
