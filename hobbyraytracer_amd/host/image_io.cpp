@@ -64,6 +64,14 @@ bool readHDR(const std::string& path, std::vector<float>& rgb, int& w, int& h, s
     int hh = 0, ww = 0;
     if (std::sscanf(line.c_str(), "-Y %d +X %d", &hh, &ww) != 2 || hh <= 0 || ww <= 0) { err = "unsupported HDR layout"; return false; }
     w = ww; h = hh;
+    // stb_image's own limit (STBI_MAX_DIMENSIONS), and a header may not promise more pixels than the bytes that follow can
+    // encode (a run-length coded scanline spends at least 4 + 8 bytes per 127 pixels, a flat one 4 per pixel): nothing
+    // of a size the file cannot back is allocated
+    if (w > (1 << 24) || h > (1 << 24)) { err = "HDR too large"; return false; }
+    {
+        const uint64_t row_min = (w < 8 || w >= 32768) ? (uint64_t)w * 4 : 4 + 8 * (((uint64_t)w + 126) / 127);
+        if ((uint64_t)h * row_min > (uint64_t)(d.size() - p)) { err = "truncated HDR"; return false; }
+    }
     rgb.assign((size_t)w * h * 3, 0.0f);
     auto convert = [](const uint8_t* in, float* out) {  // stbi__hdr_convert
         if (in[3] != 0) {
@@ -128,6 +136,13 @@ bool readPFM(const std::string& path, std::vector<float>& rgb, int& w, int& h, s
         return false;
     }
     std::fgetc(f);                                                      // the single whitespace after the scale
+    {   // the raster must be there before anything of its size is allocated
+        const long at = std::ftell(f);
+        std::fseek(f, 0, SEEK_END);
+        const long end = std::ftell(f);
+        std::fseek(f, at, SEEK_SET);
+        if (at < 0 || end < at || (uint64_t)w * (uint64_t)h * 12u > (uint64_t)(end - at)) { std::fclose(f); err = path + " is truncated"; return false; }
+    }
     rgb.resize((size_t)w * h * 3);
     bool ok = true;
     for (int y = h - 1; y >= 0 && ok; --y) ok = std::fread(&rgb[(size_t)y * w * 3], sizeof(float), (size_t)w * 3, f) == (size_t)w * 3;

@@ -437,6 +437,13 @@ bool decodeJPEG(const uint8_t* bytes, size_t n_bytes, std::vector<uint8_t>& rgb,
                     if (z.hmax % z.comp[i].h || z.vmax % z.comp[i].v) return bad("unsupported sampling factors");
                 z.mcu_x = (z.width + z.hmax * 8 - 1) / (z.hmax * 8);
                 z.mcu_y = (z.height + z.vmax * 8 - 1) / (z.vmax * 8);
+                {   // every 8x8 block costs at least one bit of entropy-coded data (its DC code; a progressive file can skip
+                    // the rest with end-of-band runs): a header that promises more blocks than the file can hold -- with a
+                    // factor 2 to spare -- is refused before planes of that size are allocated
+                    uint64_t blocks = 0;
+                    for (int i = 0; i < z.n_comp; ++i) blocks += (uint64_t)z.mcu_x * z.mcu_y * z.comp[i].h * z.comp[i].v;
+                    if (blocks / 16 > (uint64_t)n_bytes) return bad("image size does not fit the file");
+                }
                 for (int i = 0; i < z.n_comp; ++i) {
                     Component& c = z.comp[i];
                     c.w = (z.width * c.h + z.hmax - 1) / z.hmax;
