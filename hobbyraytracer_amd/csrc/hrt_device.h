@@ -806,7 +806,7 @@ __device__ inline vec3 tex_value(const DScene& sc, int tex, float u, float v, ve
     for (int depth = 0; depth < 4; ++depth) {
         const hrt_texture& t = sc.ltexs[tex];
         if (t.kind != HRT_TEX_CHECKER) return tex_leaf(sc, t, u, v);
-        float sines = gsin(10 * p.x) * gsin(10 * p.y) * gsin(10 * p.z);
+        float sines = gsin_wide(10 * p.x) * gsin_wide(10 * p.y) * gsin_wide(10 * p.z);
         tex = (sines < 0) ? t.odd : t.even;
     }
     return vec3(0, 1, 1);

@@ -137,7 +137,8 @@ HRT_HD float cos_poly(float r) {  // |r| <= pi/4
     float p = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
     return (p - 0.5f * z) + 1.0f;
 }
-// Cody-Waite reduction by pi/2 in three parts; valid for |x| < ~1e4
+// Cody-Waite reduction by pi/2 in three parts; valid for |x| < 8192 (k has 13 bits, every product is exact inside the fma).
+// Every caller but the checker texture has a bounded argument (angles in [0, 2 pi]); that one uses gsin_wide below.
 HRT_HD float reduce_pio2(float x, int& q) {
     float k = rintf(x * 0.636619772367581343f);
     q = (int)k;
@@ -145,6 +146,25 @@ HRT_HD float reduce_pio2(float x, int& q) {
     r = fmaf(-k, 4.837512969970703125e-4f, r);
     r = fmaf(-k, 7.54978995489188e-8f, r);
     return r;
+}
+// The same for any argument: beyond 8192 in fp64 with a two-part pi/2 (good to ~1e-9 up to 1e9: the checker texture of
+// a floor a few hundred kilometres wide); fp64 is IEEE on both sides, so CPU and GPU still agree bit for bit.  Beyond what
+// that can resolve (|x| > 1e15) the answer is pinned to r = 0 (sin 0, cos 1) -- the "total loss of significance" convention
+// of the fp32 libm this follows -- and to NaN for inf / NaN, like std::sin.  (Converting k to int directly, as above, is
+// undefined above 2^31, and x86 and gfx950 disagree there: a checker evaluated 7e9 units from the origin came out odd on
+// one and even on the other; tests/tools/gpu_fuzz.py seed 11081.)
+HRT_HD float reduce_pio2_wide(float x, int& q) {
+    const float ax = fabsf(x);
+    if (ax < 8192.0f) return reduce_pio2(x, q);
+    q = 0;
+    if (!(ax <= 3.4028234e38f)) return u2f(0x7fc00000u);            // inf, NaN
+    if (ax > 1e15f) return 0.0f;
+    const double xd = (double)x;
+    const double k = rint(xd * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632679489655800, xd);                   // pi/2 rounded to double ...
+    r = fma(-k, 6.12323399573676603587e-17, r);                       // ... and what the rounding left over
+    q = (int)(k - 4.0 * floor(k * 0.25));                             // k mod 4 in [0, 3]
+    return (float)r;
 }
 HRT_HD float asin_core(float a) {  // 0 <= a <= 0.5 : asin(a)
     float z = a * a;
@@ -175,6 +195,12 @@ HRT_HD void gsincos(float x, float& s_out, float& c_out) {
     c_out = (((q + 1) & 2) != 0) ? -cc : cc;
 }
 HRT_HD float gsin(float x) { float s, c; gsincos(x, s, c); return s; }
+// sin of an argument of any size (texture.cpp:20-21, the checker: sin(10 * p) of a world-space point)
+HRT_HD float gsin_wide(float x) {
+    int q; float r = detail::reduce_pio2_wide(x, q);
+    const float v = (q & 1) ? detail::cos_poly(r) : detail::sin_poly(r);
+    return (q & 2) ? -v : v;
+}
 HRT_HD float gcos(float x) { float s, c; gsincos(x, s, c); return c; }
 HRT_HD float gasin(float x) {
     float a = fabsf(x);

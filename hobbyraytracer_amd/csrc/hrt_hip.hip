@@ -205,6 +205,14 @@ __global__ void k_math_probe(int op, long long n, const float* __restrict__ in, 
             out[4 * i] = u2f(r.x); out[4 * i + 1] = u2f(r.y); out[4 * i + 2] = u2f(r.z); out[4 * i + 3] = u2f(r.w);
             break;
         }
+        // plain IEEE operations on awkward operands (denormal products, quotients, roots): what the compiler options and the
+        // hardware mode registers make of them must be what the CPU makes of them (tests/test_gpu_parity.py)
+        case 6: out[i] = in[i] * in2[i]; break;
+        case 7: out[i] = in[i] / in2[i]; break;
+        case 8: out[i] = sqrtf(in[i]); break;
+        case 9: out[i] = in[i] + in2[i]; break;
+        case 10: out[i] = fmaf(in[i], in2[i], in2[i]); break;
+        case 11: out[i] = gsin_wide(in[i]); break;
         default: out[i] = 0.0f;
     }
 }
@@ -326,10 +334,14 @@ __device__ inline rng_ctx slot_ctx(const hrt_params& pr, const RenderMap& map, u
     return ctx;
 }
 
+// The wave-level stage functions are shared by several kernels (k_wf_shade / k_wf_tail ...): they must be INLINED into each --
+// once wf_shade_task grew past the inliner's budget it became a real call, its by-reference state went to scratch
+// (600 bytes per lane) and k_wf_shade took 58 instead of 21 ms per frame (tests/test_kernel_resources.py watches for it).
+#define HRT_WAVE_FN __attribute__((always_inline)) inline
 // Preparation of one segment: analytic prims [p0, p1) in list order (closest-so-far semantics of
 // hittableList.cpp:12-19), then the ray in the space of mesh prim `mesh_prim` and the root-box filter.
 template <bool STATS>
-__device__ inline bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
+__device__ HRT_WAVE_FN bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
                                   const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled) {
     prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
     if (mesh_prim < 0) return false;
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_p
 // Scenes with several meshes: analytic prims [p0, mesh_prim) + preparation for mesh prim `mesh_prim`.  Returns the number
 // of rays queued for the traversal.
 template <bool STATS>
-__device__ inline unsigned wf_pre_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, unsigned n_local, int s0, int round, int par,
+__device__ HRT_WAVE_FN unsigned wf_pre_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, unsigned n_local, int s0, int round, int par,
                                        int p0, int mesh_prim, const WfBuf& w, unsigned task, unsigned n, unsigned lane, unsigned long long lt,
                                        unsigned& n_culled) {
     const unsigned base = task * w.T;
@@ -475,7 +487,7 @@ __device__ inline ExtMesh wf_ext_mesh(const DScene& sc, int mesh_prim) {
     return m;
 }
 template <bool STATS, class NextRange>
-__device__ inline void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, int* stack, unsigned lane,
+__device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, int* stack, unsigned lane,
                                   unsigned long long lt, int leaf_num, DCounters& cnt, NextRange next_range) {
     const float t_lo = trav_t_lo(pr.t_min, pr.quirks);
     bool has = false;
@@ -593,7 +605,7 @@ __device__ inline void missq_flush(const DScene& sc, const WfBuf& w, MissQueue& 
 // for the survivors, the preparation of their next segment.  Survivors are written compacted, in order, to the other
 // state copy.  n = live paths of the task; returns the survivors (live_out) and the rays queued for the first mesh (qn_out).
 template <bool STATS>
-__device__ inline void wf_shade_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, const WfScene& ws, unsigned n_local, int s0, int round,
+__device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, const WfScene& ws, unsigned n_local, int s0, int round,
                                      const WfBuf& w, unsigned task, unsigned n, unsigned lane, unsigned long long lt, MissQueue& mq,
                                      PathCounters& pc, unsigned& n_seg, unsigned& n_culled, unsigned& live_out, unsigned& qn_out) {
     const int par = round & 1, nxt = par ^ 1;
@@ -638,7 +650,15 @@ __device__ inline void wf_shade_task(const DScene& sc, const hrt_params& pr, con
         if (j0 + lane < n && !missed) {
             const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
             if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
-            else alive = true;
+            else {
+                alive = true;
+                // The state carries no `result`: while a path lives it is 0 -- main.cpp:66 adds attenuation * emitted, and
+                // what scatters on emits nothing -- unless the attenuation is no longer finite (garbage scenes: inf * 0),
+                // which makes that component of the pixel NaN for good.  A NaN attenuation says the same at the path's end.
+                if (ps.result.x != ps.result.x) ps.atten.x = ps.result.x;
+                if (ps.result.y != ps.result.y) ps.atten.y = ps.result.y;
+                if (ps.result.z != ps.result.z) ps.atten.z = ps.result.z;
+            }
         }
         const unsigned long long ma = __ballot(alive);
         bool enq = false;
@@ -661,7 +681,7 @@ __device__ inline void wf_shade_task(const DScene& sc, const hrt_params& pr, con
 }
 // what a shading wave adds to the device counters when it is done
 template <bool STATS>
-__device__ inline void wf_shade_counters(const WfBuf& w, DeviceCounters* counters, unsigned wave, unsigned lane, unsigned n_seg, unsigned n_culled,
+__device__ HRT_WAVE_FN void wf_shade_counters(const WfBuf& w, DeviceCounters* counters, unsigned wave, unsigned lane, unsigned n_seg, unsigned n_culled,
                                          const PathCounters& pc) {
     const unsigned seg = wave_sum(n_seg);
     if (lane == 0 && seg) w.wave_rays[wave] += (unsigned long long)seg;      // this wave's own cell: no contention
@@ -932,7 +952,8 @@ hrt_status validate(const hrt_flat_scene* f) {
         if (p.kind == HRT_PRIM_MEDIUM) {
             if (p.boundary_kind != HRT_PRIM_SPHERE && p.boundary_kind != HRT_PRIM_BOX)
                 return fail(HRT_ERR_UNSUPPORTED, "constant medium boundary must be a sphere or a box");
-            if (!(p.density > 0.0f)) return fail(HRT_ERR_INVALID, "constant medium density must be > 0");
+            // (any density is taken, as constantMedium.cpp:9 does: -1 / 0 = -inf simply never scatters, a negative one
+            // scatters "before" the boundary; the arithmetic is the oracle's, tests/scene_helpers.py random_world)
         }
         if (p.n_xforms < 0 || p.n_xforms > HRT_MAX_XFORMS) return fail(HRT_ERR_INVALID, "too many instance wrappers");
         for (int k = 0; k < p.n_xforms; ++k)
@@ -1574,8 +1595,8 @@ hrt_status hrt_closest_hit(hrt_scene* sc, const hrt_params* pr, int64_t n, const
 
 hrt_status hrt_math_probe(int device, int32_t op, int64_t n, const float* in, const float* in2, float* out) {
     HRT_API_TRY
-    if (!in || !out || n < 0 || op < 0 || op > 5) return fail(HRT_ERR_INVALID, "bad argument");
-    if ((op == 3 || op == 5) && !in2) return fail(HRT_ERR_INVALID, "in2 required");
+    if (!in || !out || n < 0 || op < 0 || op > 11) return fail(HRT_ERR_INVALID, "bad argument");
+    if ((op == 3 || op == 5 || op == 6 || op == 7 || op == 9 || op == 10) && !in2) return fail(HRT_ERR_INVALID, "in2 required");
     if (n == 0) return HRT_OK;
     HIPCHK(hipSetDevice(device));
     const size_t n_in = (size_t)n * (op == 5 ? 4 : 1), n_in2 = (size_t)n * (op == 5 ? 2 : 1), n_out = (size_t)n * (op == 5 ? 4 : 1);

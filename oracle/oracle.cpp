@@ -122,7 +122,7 @@ struct CheckeredTexture : Texture {  // texture.cpp:17-28
     const Texture *e, *o;
     CheckeredTexture(const Texture* even, const Texture* odd) : e(even), o(odd) {}
     vec3 colourValue(float u, float v, vec3 p) const override {
-        float sines = gsin(10 * p.x) * gsin(10 * p.y) * gsin(10 * p.z);
+        float sines = gsin_wide(10 * p.x) * gsin_wide(10 * p.y) * gsin_wide(10 * p.z);
         if (sines < 0) return o->colourValue(u, v, p);
         return e->colourValue(u, v, p);
     }
@@ -990,6 +990,12 @@ void oracle_math_probe(int32_t op, int64_t n, const float* in, const float* in2,
             case 2: out[i] = gacos(in[i]); break;
             case 3: out[i] = gatan2(in2[i], in[i]); break;
             case 4: out[i] = glog(in[i]); break;
+            case 6: out[i] = in[i] * in2[i]; break;
+            case 7: out[i] = in[i] / in2[i]; break;
+            case 8: out[i] = sqrtf(in[i]); break;
+            case 9: out[i] = in[i] + in2[i]; break;
+            case 10: out[i] = fmaf(in[i], in2[i], in2[i]); break;
+            case 11: out[i] = gsin_wide(in[i]); break;
             case 5: {
                 u32x4 r = philox4x32_10(f2u(in[4 * i]), f2u(in[4 * i + 1]), f2u(in[4 * i + 2]), f2u(in[4 * i + 3]),
                                         f2u(in2[2 * i]), f2u(in2[2 * i + 1]));

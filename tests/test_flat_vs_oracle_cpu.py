@@ -285,7 +285,7 @@ def test_random_worlds(built, tmp_path, tools, extreme, meshes):
     test_gpu_scenes.py runs more seeds than this one.)"""
     orc, FlatCpu = tools
     from hobbyraytracer_amd import api
-    from tests.scene_helpers import random_world
+    from tests.scene_helpers import random_world, films_equal
     for seed in range(8):
         if (extreme, meshes, seed) == (1, True, 4):
             continue   # meets the documented Q-4 residual (DESIGN.md section 2): a ray with d.x / |d| = 9e-6 on the origin-chosen shear axis
@@ -295,7 +295,7 @@ def test_random_worlds(built, tmp_path, tools, extreme, meshes):
             a, sa = FlatCpu(hs.flat_ptr).render_tile(hs.camera(40, 40), p)
             b, sb = orc.World(hs.flat_ptr).render_tile(hs.camera(40, 40), p)
             assert sa.rays == sb.rays, (seed, q)
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, q)
+            assert films_equal(a, b), (seed, q)
 
 
 def test_nan_rays_and_nan_t_max_from_a_degenerate_triangle(built, tmp_path, tools):

@@ -55,7 +55,7 @@ def _rng_rays(n, seed, lo, hi, target_lo, target_hi):
 
 
 def test_math_kernels_bit_exact(built):
-    """sin / cos / acos / atan2 / log / philox: CPU value == GPU value, bit for bit."""
+    """sin / cos / acos / atan2 / log / philox / the wide-range sine / plain IEEE operations: CPU value == GPU value, bit for bit."""
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
     r = np.random.default_rng(1)
@@ -72,6 +72,25 @@ def test_math_kernels_bit_exact(built):
     ctr = r.integers(0, 2**32, size=(50000, 4), dtype=np.uint32).view(np.float32)
     key = r.integers(0, 2**32, size=(50000, 2), dtype=np.uint32).view(np.float32)
     assert np.array_equal(orc.math_probe(5, ctr, key).view(np.uint32), api.math_probe(5, ctr, key).view(np.uint32))
+    # the checker's sine takes world-space points of ANY size (a hit 7e9 units away gave odd on the CPU and even on the GPU
+    # while the range reduction converted an out-of-range float to int: tests/tools/gpu_fuzz.py seed 11081): every
+    # magnitude up to FLT_MAX, inf and NaN
+    mag = 10.0 ** r.uniform(-6, 38.5, 300000)
+    w = np.concatenate([mag * r.choice([-1.0, 1.0], mag.size), [8191.9995, 8192.0, -8192.0, 1e15, 1.0000001e15, 3.4028234e38, np.inf, -np.inf, np.nan]]).astype(np.float32)
+    a, b = orc.math_probe(11, w), api.math_probe(11, w)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    fin = np.isfinite(w) & (np.abs(w) <= 1e9)
+    assert np.abs(a[fin] - np.sin(w[fin].astype(np.float64))).max() < 2e-6 and np.abs(a[np.isfinite(w)]).max() <= 1.0
+    assert np.array_equal(orc.math_probe(11, x).view(np.uint32), orc.math_probe(0, x).view(np.uint32))     # == gsin where gsin is valid
+    # plain IEEE operations on awkward operands (denormal products, quotients, roots, sums, fma): the GPU's answer is numpy's
+    a1 = np.concatenate([np.array([1e-20, 1e-30, 3e-39, 1e-38, 1.5e-45, 1e-25, -1e-20, 2e-38]), r.uniform(0.5, 2, 20000) * 10.0 ** r.uniform(-44, -18, 20000)]).astype(np.float32)
+    b1 = np.concatenate([np.array([1e-20, 1e-10, 0.5, 0.25, 3.0, 1e-20, 1e-20, 0.3]), r.uniform(0.5, 2, 20000) * 10.0 ** r.uniform(-25, 5, 20000)]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        for op, ref in ((6, a1 * b1), (7, a1 / b1), (8, np.sqrt(np.abs(a1))), (9, a1 + b1)):
+            g = api.math_probe(op, np.abs(a1) if op == 8 else a1, b1)
+            assert np.array_equal(g.view(np.uint32), ref.astype(np.float32).view(np.uint32)), f"op {op}"
+            assert np.array_equal(g.view(np.uint32), orc.math_probe(op, np.abs(a1) if op == 8 else a1, b1).view(np.uint32)), f"op {op}"
+        assert np.array_equal(api.math_probe(10, a1, b1).view(np.uint32), orc.math_probe(10, a1, b1).view(np.uint32))
 
 
 @pytest.mark.parametrize("quirks", ["reference", "fixed"])

@@ -309,17 +309,13 @@ def test_random_worlds(built, tmp_path, monkeypatch, extreme, meshes):
     mesh-by-mesh walk with analytic primitives in between (k_wf_pre) is exercised."""
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
-    from tests.scene_helpers import random_world
+    from tests.scene_helpers import random_world, films_equal
     rendered = 0
     for seed in range(24):
         if (extreme, meshes, seed) == (1, True, 4):
             continue   # meets the documented Q-4 residual (DESIGN.md section 2), see the CPU twin of this test
         hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme, meshes=meshes), str(tmp_path))
-        try:
-            dev = api.DeviceScene(hs.flat_ptr, 0)
-        except api.HrtError as e:   # hrt_scene_create refuses what would divide by zero on the device (density <= 0)
-            assert extreme and "density" in str(e), (seed, str(e))
-            continue
+        dev = api.DeviceScene(hs.flat_ptr, 0)
         rendered += 1
         world = orc.World(hs.flat_ptr)
         cam = hs.camera(40, 40)
@@ -329,9 +325,9 @@ def test_random_worlds(built, tmp_path, monkeypatch, extreme, meshes):
                 monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
                 img, st = dev.render_tile(cam, api.default_params(40, 40, 4, quirks=q, stats=True, megakernel=mega))
                 assert st.rays == sr.rays, (seed, q, tail, mega)
-                assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (seed, q, tail, mega)
+                assert films_equal(img, ref), (seed, q, tail, mega)
         dev.close()
-    assert rendered >= 12
+    assert rendered >= 23
 
 
 @pytest.mark.parametrize("chain", ["", "Y", "Q", "S", "T", "YQ", "QS", "ST", "YQS", "YQT", "QST", "YST", "YQST"])
@@ -373,6 +369,28 @@ def test_nan_rays_and_nan_t_max_from_a_degenerate_triangle(built, tmp_path, monk
             img, st = dev.render_tile(cam, api.default_params(32, 32, 4, quirks=q, stats=True, megakernel=mega))
             assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits), (q, tail, mega)
             assert films_equal(img, ref), (q, tail, mega)
+    dev.close()
+
+
+def test_wavefront_pipeline_keeps_the_nan_of_an_infinite_attenuation(built, tmp_path, monkeypatch):
+    """random_world seed 14563 (extreme): a path whose attenuation has become infinite scatters on; main.cpp:66 adds
+    attenuation * emitted = inf * 0 = NaN to the pixel at that bounce.  The pipeline's path state carries no running result
+    (it is 0 while a path lives, for finite attenuations), so it reported -inf where the reference has NaN, in 15 % of this
+    film's pixels; the NaN is now folded into the attenuation.  Found by tests/tools/gpu_fuzz.py once negative medium
+    densities were let through."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import random_world, films_equal
+    hs = api.HostScene(random_world(tmp_path, 14563, 1), str(tmp_path))
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    cam = hs.camera(40, 40)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(40, 40, 4, quirks=q, stats=True))
+        assert np.isnan(ref).any(2).sum() > 100
+        for tail, mega in (("1", False), ("1000", False), ("3", False), ("1", True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(40, 40, 4, quirks=q, stats=True, megakernel=mega))
+            assert st.rays == sr.rays and films_equal(img, ref), (q, tail, mega)
     dev.close()
 
 
