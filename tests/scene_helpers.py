@@ -60,14 +60,16 @@ def soup_scene(tmp_path, kind, scale=1.0, offset=(0.0, 0.0, 0.0), n=300, seed=7)
 
 
 def _v3(v): return "[%.9g, %.9g, %.9g]" % tuple(v)
-def random_world(tmp_path, seed, extreme, meshes=False):
+def random_world(tmp_path, seed, extreme, meshes=False, images=False):
     """A random world of analytic primitives (spheres, rects, boxes, media, free triangles) on a 0.5 lattice, so that
     coplanar / coincident surfaces are common, with random transform chains and materials and a few objects listed twice
     with another material (exact ties between primitives).  `extreme` adds degenerate parameters: zero / negative radii and
     box dimensions, reversed or empty rect ranges, negative and huge scales, ior 1 / 0.5 / 1e-3 / 50, roughness 2.5,
     medium densities 0 / 1e-6 / 1e4 / -1.  `meshes` inserts 1..3 triangle meshes (a soup, a smooth-shaded sphere, a lattice-
     aligned grid that is coplanar with rects and box faces) at random places of the object list, under wrapper chains of their
-    own: the wavefront pipeline walks the list mesh by mesh, analytic primitives in between (k_wf_pre)."""
+    own: the wavefront pipeline walks the list mesh by mesh, analytic primitives in between (k_wf_pre).  `images` adds a
+    7x5 PNG image texture (as albedo and as roughness) and a 16x8 Radiance environment map as background, so texel fetches
+    see the (u, v) every primitive kind produces -- including the NaN and out-of-range ones of degenerate primitives."""
     import re
     import numpy as np
     d = tmp_path
@@ -171,6 +173,21 @@ def random_world(tmp_path, seed, extreme, meshes=False):
        f"camera:\n    position: {_v3(cam)}\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: %.6g\n    focal_distance: 7\n    background: {_v3(col())}\n"%r.choice([0,0.1])+
        "textures:\n  - name: chk\n    type: checkered\n    even: [0.9, 0.9, 0.9]\n    odd: [0.1, 0.3, 0.1]\n"
        "materials:\n"+"".join(mats)+"objects:\n"+"".join(objs))
+    if images:
+        from hobbyraytracer_amd import api
+        ri = np.random.default_rng(2 * 10**6 + seed)
+        api.write_image(str(d / "ftex.png"), ri.integers(0, 256, (5, 7, 3)).astype(np.uint8))
+        api.write_hall_hdr(str(d / "fenv.hdr"), 16, 8)
+        y = y.replace("textures:\n", "textures:\n  - name: img\n    type: image\n    path: ftex.png\n  - name: env\n    type: environment\n    path: fenv.hdr\n", 1)
+        y = y.replace("albedo: chk", "albedo: img")
+        lines = y.split("\n")
+        kind = ""
+        for k, line in enumerate(lines):
+            if line.startswith("    type: "): kind = line[10:]
+            if line.startswith("    albedo: [") and kind in ("lambertian", "metal", "diffuse_light") and ri.random() < 0.4: lines[k] = "    albedo: img"
+            elif line.startswith("    roughness: ") and kind == "metal" and ri.random() < 0.5: lines[k] = "    roughness: img"
+            elif line.startswith("    background: [") and ri.random() < 0.6: lines[k] = "    background: env"
+        y = "\n".join(lines)
     open(d/"f.yaml","w").write(y)
     return str(d/"f.yaml")
 

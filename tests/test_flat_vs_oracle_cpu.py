@@ -289,7 +289,7 @@ def test_random_worlds(built, tmp_path, tools, extreme, meshes):
     for seed in range(8):
         if (extreme, meshes, seed) == (1, True, 4):
             continue   # meets the documented Q-4 residual: a ray with d.x / |d| = 9e-6 on the origin-chosen shear axis
-        hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme, meshes=meshes), str(tmp_path))
+        hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme, meshes=meshes, images=meshes), str(tmp_path))
         for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
             p = api.default_params(40, 40, 4, quirks=q, stats=True)
             a, sa = FlatCpu(hs.flat_ptr).render_tile(hs.camera(40, 40), p)

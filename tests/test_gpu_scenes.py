@@ -314,7 +314,7 @@ def test_random_worlds(built, tmp_path, monkeypatch, extreme, meshes):
     for seed in range(24):
         if (extreme, meshes, seed) == (1, True, 4):
             continue   # meets the documented Q-4 residual, see the CPU twin of this test
-        hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme, meshes=meshes), str(tmp_path))
+        hs = api.HostScene(random_world(tmp_path, 1000 * extreme + seed, extreme, meshes=meshes, images=meshes), str(tmp_path))
         dev = api.DeviceScene(hs.flat_ptr, 0)
         rendered += 1
         world = orc.World(hs.flat_ptr)
