@@ -240,7 +240,10 @@ class HostScene:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:                     # at interpreter shutdown the module globals may already be gone
+            self.close()
+        except Exception:
+            pass
 
     @property
     def film(self):
@@ -372,7 +375,10 @@ class DeviceScene:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def render_tile(self, cam, params, rect=None):
         """-> (h, w, 3) fp32 linear film tile, Stats."""
