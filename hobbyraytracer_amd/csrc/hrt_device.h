@@ -445,6 +445,8 @@ __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4
 struct TravState {
     float closest;        // t_max, shrinking
     int best;             // closest accepted triangle so far (mesh-local index) or -1
+    // (no member of its own for the near-tie note: while there is no self-hit, `self_tri` holds a triangle whose t lies within
+    //  2 ulp of `closest`, or -1 -- see trav_result; the first self-hit overwrites it, and then it is no longer needed)
     // Self-hits (Q-2): a candidate with t < t_min.  In the reference, once one is accepted every later
     // BOX test fails (bvh.cpp:71 gets t_max = rec.t < t_min), so the one in the FIRST lowest-level node of
     // its own tree's depth-first walk wins, whatever its distance (the two triangles of that one node are
@@ -557,7 +559,9 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
         if (farther && (ts.best < 0 || ts.selfhit || fabsf(ev.tScaled - lim) > 1e-6f * fabsf(lim))) continue;
         const float invDet = 1 / ev.det;
         const float t = ev.tScaled * invDet;
-        if (farther && t != ts.closest) continue;
+        // within 2 ulp of the hit so far (both positive floats: their bit patterns are ordered like their values)?
+        const bool near = ts.best >= 0 && (unsigned)(__float_as_int(t) - __float_as_int(ts.closest) + 2) <= 4u;
+        if (farther && !near) continue;
         if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
         const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
         // accept_box costs six IEEE divisions and almost always passes.  Shortcut with the SAME outcome: if t is
@@ -595,39 +599,55 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
             }
             if (!ts.selfhit) { ts.selfhit = true; ts.closest = t_min * 1.0001f; }
         } else if (!ts.selfhit) {
-            // Ties.  triangle.cpp:106-109 keep a candidate X unless tScaled_X is strictly beyond t_best * det_X in fp32,
-            // and the reference meets the triangles in the fixed left-then-right order of ITS tree (bvh.cpp:74-75,
-            // ranked by tri_ref_order), this tree in another.  With t_X == t_best (duplicated or coplanar faces, a shared
-            // edge met to the last bit, far-away origins) the outcome of that sequential rule is, with "X self-passes"
-            // := X passes the comparison against its own rounded t:
-            //    both self-pass -> the one met LAST wins      neither -> the one met FIRST wins
-            //    only one self-passes -> that one wins, whatever the order
-            // X self-passes iff it was not `farther` here (t_best == t_X); the hit so far carries its own flag.
-            const bool self_x = !farther;
-            bool take = true;
-            if (ts.best >= 0 && !(t < ts.closest)) {
-                const bool self_b = (ts.best & HRT_TIE_SELF) != 0;
-                const uint32_t ord_x = (uint32_t)__float_as_int(bmn.w);
-                const uint32_t ord_b = (uint32_t)__float_as_int(tbox[2 * (ts.best & ~HRT_TIE_SELF)].w);
-                take = self_x != self_b ? self_x : (self_x ? ord_x > ord_b : ord_x < ord_b);
-            }
-            if (take) {
+            // Ties and near-ties.  triangle.cpp:106-109 keep a candidate X unless tScaled_X is strictly beyond t_best * det_X
+            // in fp32, and the reference meets the triangles in the fixed left-then-right order of ITS tree (bvh.cpp:74-75,
+            // ranked by tri_ref_order), this tree in another.  Between two hits whose t lie within an ulp or two (a shared
+            // edge, duplicated or coplanar faces, far-away origins) that comparison is not a total order -- the later one
+            // can be turned down although its t is an ulp smaller, or taken although it is equal -- so the winner depends on
+            // who is met first.  Here the walk keeps the closer one as usual and remembers the other (in `self_tri`, unused until a self-hit); trav_result
+            // replays the pair in the reference's order.
+            if (farther) ts.self_tri = (int)ti;
+            else {
+                if (near) ts.self_tri = ts.best;
                 ts.closest = t;
-                // does this hit pass triangle.cpp:106-109 against its own t?
-                const float own = t * ev.det;
-                const bool self_now = farther ? false : (ev.det < 0 ? !(ev.tScaled < own) : !(ev.tScaled > own));
-                ts.best = (int)ti | (self_now ? HRT_TIE_SELF : 0);
+                ts.best = (int)ti;
             }
         }
     }
     if (ts.sp > 0) { --ts.sp; ts.cur = stack[ts.sp * HRT_BLOCK]; }
     else ts.cur = HRT_TRAV_DONE;
 }
-// Result of a finished traversal: winning triangle (or -1) and its t.
-__device__ inline int trav_result(const TravState& ts, float& t_out) {
+// Result of a finished traversal: winning triangle (or -1) and its t.  A remembered near-tie (ts.self_tri without a self-hit) is settled the way the
+// reference's walk would have: F = the one of the pair its tree meets first, S = the other; F stands unless S, tested with
+// t_max = t_F (bvh.cpp:75 / the running closest), passes triangle.cpp:106-109 and its leaf-level box (aabb.h:26-39).
+__device__ inline int trav_result(const TravState& ts, const float4* __restrict__ tpos, const float4* __restrict__ tbox, const MeshRay& r,
+                                  float t_min, float& t_out) {
     if (ts.selfhit) { t_out = ts.self_t; return ts.self_tri & ~HRT_TIE_SELF; }
     t_out = ts.closest;
-    return ts.best < 0 ? -1 : (ts.best & ~HRT_TIE_SELF);
+    const int alt = ts.self_tri;
+    if (ts.best < 0 || alt < 0 || alt == ts.best) return ts.best;
+    const uint32_t ord_b = (uint32_t)__float_as_int(tbox[2 * ts.best].w), ord_a = (uint32_t)__float_as_int(tbox[2 * alt].w);
+    const int F = ord_a < ord_b ? alt : ts.best, S = ord_a < ord_b ? ts.best : alt;
+    // (one evaluation body run twice, not two bodies: the registers of k_wf_ext are counted, tests/test_kernel_resources.py)
+    TriEval eS;
+    float tF = 0.0f;
+#if defined(__HIPCC__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int k = 0; k < 2; ++k) {
+        const int T = k == 0 ? F : S;
+        const float4 q0 = tpos[3 * T + 0], q1 = tpos[3 * T + 1], q2 = tpos[3 * T + 2];
+        if (!tri_eval(r.tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), eS)) return ts.best;
+        if (k == 0) tF = eS.tScaled * (1 / eS.det);
+    }
+    const float tS = eS.tScaled * (1 / eS.det);
+    // a stale note (the pair it was about has been overtaken by a clearly closer hit): nothing to settle
+    if ((unsigned)(__float_as_int(tS) - __float_as_int(tF) + 2) > 4u) return ts.best;
+    const float lim = tF * eS.det;
+    const bool farther = eS.det < 0 ? eS.tScaled < lim : eS.tScaled > lim;
+    const bool s_wins = !farther && accept_box(tbox[2 * S], tbox[2 * S + 1], r.o, r.d, t_min, tF);
+    t_out = s_wins ? tS : tF;
+    return s_wins ? S : F;
 }
 
 // Whole traversal for one lane (megakernel / test kernels).
@@ -650,7 +670,7 @@ __device__ inline int bvh_traverse(const DScene& sc, int mi /* mesh index */, ve
         while (trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
         if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, t_min, quirks, stack, cnt);
     }
-    return trav_result(ts, t_out);
+    return trav_result(ts, tpos, tbox, r, t_min, t_out);
 }
 
 // triangle.cpp:111-128 for the winning triangle

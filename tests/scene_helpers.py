@@ -246,3 +246,30 @@ def nan_ray_scene(tmp_path):
         "  - type: xz_rect\n    x: [-4, 4]\n    z: [-4, 4]\n    k: -1.2\n    material: a\n"
         "  - type: mesh\n    path: quad.obj\n    material: b\n    transform:\n        translate: [0, 0, -2]\n")
     return str(tmp_path / "nan.yaml")
+
+
+def many_meshes_scene(tmp_path, n_mesh):
+    """n_mesh instances of two OBJ files (a small teapot, a quad) under rotate_y + translate, a sphere after each, a floor:
+    more meshes than k_wf_tail takes (HRT_TAIL_MAX_MESHES = 4), glass, metal and diffuse.  The teapot's shared edges make
+    1-ulp near-ties between neighbouring triangles likely: the 5-mesh scene was the first to show one whose winner depends
+    on the visiting order (hrt_device.h trav_result)."""
+    import numpy as np
+    from hobbyraytracer_amd import api
+    api.write_teapot_obj(str(tmp_path / "teapot.obj"), 0.1)
+    with open(tmp_path / "quad.obj", "w") as f:
+        f.write("v -0.6 -0.6 0\nv 0.6 -0.6 0\nv 0.6 0.6 0.2\nv -0.6 0.6 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n")
+    r = np.random.default_rng(n_mesh)
+    objs = ""
+    for i in range(n_mesh):
+        pos = r.uniform(-2, 2, 3)
+        objs += "  - type: mesh\n    path: %s\n    material: %s\n    transform:\n        rotate_y: %.3f\n        translate: [%.3f, %.3f, %.3f]\n" % (
+            "teapot.obj" if i % 3 == 0 else "quad.obj", ["a", "b", "g"][i % 3], r.uniform(0, 360), pos[0], pos[1] * 0.5, pos[2])
+        objs += "  - type: sphere\n    center: [%.3f, %.3f, %.3f]\n    radius: 0.3\n    material: %s\n" % (pos[0] + 0.8, pos[1] * 0.5 + 0.5, pos[2], ["b", "g", "a"][i % 3])
+    (tmp_path / "many.yaml").write_text(
+        "film:\n    width: 48\n    height: 48\n    samples: 4\n    output: o.png\n"
+        "camera:\n    position: [0.5, 1.5, 9]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: 0\n    focal_distance: 9\n"
+        "    background: [0.6, 0.7, 0.9]\n"
+        "materials:\n  - name: a\n    type: lambertian\n    albedo: [0.8, 0.4, 0.3]\n  - name: b\n    type: metal\n    albedo: [0.8, 0.8, 0.7]\n"
+        "    roughness: 0.1\n  - name: g\n    type: dielectric\n    ior: 1.5\n"
+        "objects:\n" + objs + "  - type: xz_rect\n    x: [-6, 6]\n    z: [-6, 6]\n    k: -1.5\n    material: a\n")
+    return str(tmp_path / "many.yaml")

