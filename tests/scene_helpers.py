@@ -248,7 +248,7 @@ def nan_ray_scene(tmp_path):
     return str(tmp_path / "nan.yaml")
 
 
-def many_meshes_scene(tmp_path, n_mesh):
+def many_meshes_scene(tmp_path, n_mesh, seed=None):
     """n_mesh instances of two OBJ files (a small teapot, a quad) under rotate_y + translate, a sphere after each, a floor:
     more meshes than k_wf_tail takes (HRT_TAIL_MAX_MESHES = 4), glass, metal and diffuse.  The teapot's shared edges make
     1-ulp near-ties between neighbouring triangles likely: the 5-mesh scene was the first to show one whose winner depends
@@ -258,7 +258,7 @@ def many_meshes_scene(tmp_path, n_mesh):
     api.write_teapot_obj(str(tmp_path / "teapot.obj"), 0.1)
     with open(tmp_path / "quad.obj", "w") as f:
         f.write("v -0.6 -0.6 0\nv 0.6 -0.6 0\nv 0.6 0.6 0.2\nv -0.6 0.6 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n")
-    r = np.random.default_rng(n_mesh)
+    r = np.random.default_rng(n_mesh if seed is None else seed)
     objs = ""
     for i in range(n_mesh):
         pos = r.uniform(-2, 2, 3)
