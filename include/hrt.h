@@ -285,8 +285,9 @@ hrt_status hrt_render_stripes_device(hrt_scene* scene, const hrt_camera* cam, co
  * after which the buffer is bit-identical to a one-shot render with the same params, however the samples
  * were batched.  The buffer plus the next sample index is the whole checkpoint of a render: it can be copied out,
  * stored, and continued later (the row layout depends on rows_per_block / rank / n_ranks only).  Between passes a
- * preview is accum / samples_done.  Wavefront pipeline only: HRT_FLAG_MEGAKERNEL with a partial range is
- * HRT_ERR_UNSUPPORTED. */
+ * preview is accum / samples_done.  sample_count < 0 means "all that are left" (params->samples - sample_first); a range
+ * outside [0, params->samples) or an empty one is HRT_ERR_INVALID.  Wavefront pipeline only: HRT_FLAG_MEGAKERNEL with a
+ * partial range is HRT_ERR_UNSUPPORTED. */
 hrt_status hrt_render_stripes_accumulate_device(hrt_scene* scene, const hrt_camera* cam, const hrt_params* params,
                                                 int32_t rows_per_block, int32_t rank, int32_t n_ranks, float* d_accum,
                                                 int32_t sample_first, int32_t sample_count, void* stream);
