@@ -551,7 +551,7 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
 // DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
 // leave room for more resident blocks per CU (20 or 24 entries: 6 blocks, the VGPR limit; 32 entries: 4).
 template <bool STATS, int DEPTH>
-__global__ __launch_bounds__(HRT_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w,
+__global__ __launch_bounds__(HRT_BLOCK) __attribute__((amdgpu_waves_per_eu(DEPTH <= 24 ? 6 : 5, DEPTH <= 24 ? 6 : 5))) void k_wf_ext(DScene sc, hrt_params pr, int mesh_prim, int par, WfBuf w,
                                                       DeviceCounters* counters, int leaf_num) {
     __shared__ int s_stack[DEPTH * HRT_BLOCK];
     const unsigned lane = threadIdx.x & 63u;
