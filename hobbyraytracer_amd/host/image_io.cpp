@@ -27,6 +27,8 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out) {
     f.seekg(0, std::ios::end);
     std::streamoff n = f.tellg();
     f.seekg(0);
+    // a directory opens like a file and reports a size of 2^63 - 1 (or -1); nothing this reads is anywhere near a terabyte
+    if (!f || n < 0 || (unsigned long long)n > (1ull << 40)) return false;
     out.resize((size_t)n);
     if (n) f.read((char*)out.data(), n);
     return (bool)f;
@@ -141,7 +143,7 @@ bool readPFM(const std::string& path, std::vector<float>& rgb, int& w, int& h, s
         std::fseek(f, 0, SEEK_END);
         const long end = std::ftell(f);
         std::fseek(f, at, SEEK_SET);
-        if (at < 0 || end < at || (uint64_t)w * (uint64_t)h * 12u > (uint64_t)(end - at)) { std::fclose(f); err = path + " is truncated"; return false; }
+        if (at < 0 || end < at || end == 0x7fffffffffffffffl || (uint64_t)w * (uint64_t)h * 12u > (uint64_t)(end - at)) { std::fclose(f); err = path + " is truncated"; return false; }
     }
     rgb.resize((size_t)w * h * 3);
     bool ok = true;

@@ -212,3 +212,14 @@ def test_png_reader_matches_the_references_stb_on_every_flavour(built):
     for name in exp.files:
         got = api.read_png(os.path.join(here, "png", name))
         assert got.shape == exp[name].shape and np.array_equal(got, exp[name]), name
+
+
+def test_readers_refuse_a_directory(built, tmp_path):
+    """A directory opens like a file on Linux and reports a size of 2^63 - 1: the readers must say "cannot open", not try to
+    allocate that (found by tests/tools/fuzz_host.cpp: a mutated YAML path pointed the environment-map loader at the
+    asset directory itself)."""
+    from hobbyraytracer_amd import api
+    (tmp_path / "adir").mkdir()
+    for fn in (api.read_hdr, api.read_png, api.read_jpeg, api.read_pfm):
+        with pytest.raises(api.HrtError):
+            fn(str(tmp_path / "adir"))
