@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
     std::shared_ptr<Film> film = scene.getFilm();
     if (sw > 0 || spp > 0) {
         film_desc f = film->getFilm();
+        if (sw > 0 && (sw < 2 || sh < 2 || (long long)sw * sh > (1ll << 30))) { std::cerr << "--size: 2x2 up to 2^30 pixels" << std::endl; return 2; }
         scene.setFilmSize(sw > 0 ? sw : f.width, sh > 0 ? sh : f.height, spp > 0 ? spp : f.samples);
     }
     if (!out.empty()) film->setOutput(out);

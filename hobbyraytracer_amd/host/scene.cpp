@@ -103,6 +103,8 @@ int Scene::loadScene(std::string path, std::string assetDirArg) {
             int samples = getInt("samples", filmNode);
             std::string outputPath = getString("output", filmNode);
             if (w < 2 || h < 2 || samples < 1) throw ParseError(filmNode.line, "film needs width, height >= 2 and samples >= 1");
+            // what the device path takes (hrt_hip.hip check_params): refused here, before a film of that size is allocated
+            if ((long long)w * (long long)h > (1ll << 30)) throw ParseError(filmNode.line, "film larger than 2^30 pixels");
             film = std::make_shared<Film>(w, h, samples, outputPath);
         } else {
             std::cout << "Must specify film descriptor!" << std::endl;

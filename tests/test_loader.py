@@ -273,3 +273,13 @@ objects:
 """
     hs = _load(tmp_path, text)
     assert hs.film == (8, 8, 1, "a b.png") and hs.flat.n_prims == 1
+
+
+def test_film_size_is_bounded_before_it_is_allocated(built, tmp_path):
+    """A scene file asking for a 10^5 x 10^5 film is refused by the loader (the device path takes 2^30 pixels at most), not
+    answered with a terabyte allocation (found by tests/tools/fuzz_host.cpp)."""
+    from hobbyraytracer_amd import api
+    (tmp_path / "big.yaml").write_text("film:\n    width: 100000\n    height: 100000\n    samples: 1\n    output: o.png\n")
+    with pytest.raises(api.HrtError) as e:
+        api.HostScene(str(tmp_path / "big.yaml"), str(tmp_path))
+    assert "2^30" in str(e.value)
