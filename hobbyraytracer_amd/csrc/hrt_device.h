@@ -30,6 +30,12 @@ struct DScene {
     const float4* tri_pos;   // 3 x float4 per triangle: v0.xyz_, v1.xyz_, v2.xyz_
     const float4* tri_attr;  // 4 x float4 per triangle: n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y _
     const float4* tri_box;   // 2 x float4 per triangle: reference leaf-level box (min.xyz_, max.xyz_)
+    // The reference's own tree, threaded in preorder (hrt_pack.h pack_ref_tree), for ref_walk below:
+    const uint4* rnodes;     // 2 x uint4 per BVHNode: min.xyz skip | max.xyz (inner: 0x80000000 | right child; leaf: (first << 1) | (count - 1))
+    const float4* rtris;     // 3 x float4 per triangle in the reference's test order: v0.xyz index | v1.xyz_ | v2.xyz_
+    const uint4* rmesh;      // per mesh: first node, node count, first triangle in rtris, 0
+    float q4_route_a2;       // rays with (|d| / |d[kZ]|)^2 above this take ref_walk (q4_risky)
+    int32_t ref_fold_all;    // tests: bvh_traverse (megakernel, test kernels) takes ref_fold instead of ref_walk where it is valid
     const uint8_t* texels_u8;
     const float* texels_f32;
     int32_t n_prims;
@@ -386,6 +392,96 @@ __device__ inline bool accept_box(float4 bmn, float4 bmx, vec3 o, vec3 d, float 
     return true;
 }
 
+// ------------------------------------------------------------------ BVHNode::hit verbatim (bvh.cpp:69-78) for the rays of quirk Q-4
+// ITriangle::hit takes its shear axis from the ray ORIGIN (triangle.cpp:70, Q-4).  When the direction component on that
+// axis is small against |d|, the sheared coordinates are stretched by A = |d| / |d[kZ]| and the computed t of a triangle
+// seen edge-on loses its digits: at A = 200 a silhouette triangle truly met at t = 1.34937 reports 1.34900 -- in FRONT of
+// its own leaf box, and of the neighbour (1.34901) that is truly closer.  The reference keeps whichever of the two ITS
+// walk meets first: a first hit shrinks t_max, and BVHNode::hit (bvh.cpp:71) then drops every box that starts beyond it,
+// although the triangle inside would have reported a still smaller t.  No other tree can reproduce that (measured on the
+// teapot against the oracle, tests/tools/q4_study.py: one differing hit in 1.4e6 for A in [180, 320), one in 10^4 at
+// A = 2000, one in 40 beyond 3e4; none in 5.6e6 hits below A = 178), so such rays walk the reference's own tree, node by
+// node in its order, with its box test and its triangle test as written.  The tree is threaded (pack_ref_tree): the walk
+// is a loop over node indices without a stack -- a node whose box fails, or a leaf, continues at its `skip`.
+// Default threshold A = 128: 0.8 % of isotropic rays.
+#define HRT_Q4_ROUTE_A_DEFAULT 128.0f
+__device__ inline bool q4_risky(const TriRay& tr, vec3 d, uint32_t quirks, float route_a2) {
+    // (sZ = 1 / d[kZ]; an exactly zero component gives inf > a2: routed, and every triangle test then yields NaN as in the
+    //  reference; a NaN direction compares false and stays with the culling traversal and its NaN rules.)
+    return (quirks & HRT_Q4_SHEAR_FROM_ORIGIN) && tr.sZ * tr.sZ * dot(d, d) > route_a2;
+}
+// Returns the winning triangle (mesh-local index) or -1; t_out = its t.  t_max may be +inf, never NaN (mesh_t_max).
+// (The box / triangle tests of these rays are NOT added to the STATS counters: the three implementations -- this walk, ref_fold,
+//  the pipeline's level walk -- visit different numbers of nodes, and the counters are defined by the culling traversal.)
+template <bool STATS>
+__device__ inline int ref_walk(const uint4* __restrict__ rn, const float4* __restrict__ rt, uint32_t node_count, vec3 o, vec3 d,
+                               const TriRay& tr, float t_min, float t_max, uint32_t quirks, float& t_out, DCounters& cnt) {
+    int best = -1;
+    uint32_t i = 0;
+    while (i < node_count) {
+        const uint4 A = rn[2 * i], B = rn[2 * i + 1];
+        float4 bmn, bmx;
+        bmn.x = u2f(A.x); bmn.y = u2f(A.y); bmn.z = u2f(A.z); bmn.w = 0.0f;
+        bmx.x = u2f(B.x); bmx.y = u2f(B.y); bmx.z = u2f(B.z); bmx.w = 0.0f;
+        if (!accept_box(bmn, bmx, o, d, t_min, t_max)) { i = A.w; continue; }      // bvh.cpp:71
+        if (B.w & 0x80000000u) { ++i; continue; }                                    // bvh.cpp:74: left is the next node
+        const uint32_t first = B.w >> 1, count = (B.w & 1u) + 1u;
+        for (uint32_t k = 0; k < count; ++k) {                                      // bvh.cpp:74-75 over ITriangles
+            const float4 q0 = rt[3 * (first + k) + 0], q1 = rt[3 * (first + k) + 1], q2 = rt[3 * (first + k) + 2];
+            TriEval ev;
+            if (!tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;
+            const float lim = t_max * ev.det;                                        // triangle.cpp:106-109
+            if (ev.det < 0 && (ev.tScaled >= 0 || ev.tScaled < lim)) continue;
+            else if (ev.det > 0 && (ev.tScaled <= 0 || ev.tScaled > lim)) continue;
+            const float invDet = 1 / ev.det;
+            const float t = ev.tScaled * invDet;
+            if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
+            t_max = t;                                                               // bvh.cpp:75: right gets rec.t
+            best = (int)f2u(q0.w);
+        }
+        i = A.w;
+    }
+    t_out = t_max;
+    return best;
+}
+
+// What ref_walk computes, without the tree: a fold over ALL triangles in the tree's depth-first order (rt), each candidate
+// gated by the box of its lowest node only (tbox: mesh-local triangle -> that box + its (node << 1) | side code).  The
+// wavefront pipeline runs this fold with a whole wave per ray (hrt_hip.hip wf_ref_fold, where the argument is spelled
+// out); this is the same thing one triangle after the other, for the CPU check of the two against each other
+// (tests/test_flat_vs_oracle_cpu.py) and for the test kernels (DScene::ref_fold_all).  Not valid for rays with an exactly
+// zero direction component.
+template <bool STATS>
+__device__ inline int ref_fold(const float4* __restrict__ rt, const float4* __restrict__ tbox, uint32_t tri_count, vec3 o, vec3 d, const TriRay& tr,
+                               float t_min, float t_max, uint32_t quirks, float& t_out, DCounters& cnt) {
+    int best = -1;
+    uint32_t cur_node = 0xffffffffu;
+    bool node_ok = false;
+    for (uint32_t p = 0; p < tri_count; ++p) {
+        const float4 q0 = rt[3 * p + 0], q1 = rt[3 * p + 1], q2 = rt[3 * p + 2];
+        TriEval ev;
+        if (!tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;
+        if ((ev.det < 0 && ev.tScaled >= 0) || (ev.det > 0 && ev.tScaled <= 0)) continue;
+        const uint32_t ti = f2u(q0.w);
+        const float4 bmn = tbox[2 * ti], bmx = tbox[2 * ti + 1];
+        const uint32_t node = f2u(bmn.w) >> 1;
+        if (node != cur_node) {
+            cur_node = node;
+            node_ok = accept_box(bmn, bmx, o, d, t_min, t_max);
+        }
+        if (!node_ok) continue;
+        const float lim = t_max * ev.det;
+        if (ev.det < 0 && ev.tScaled < lim) continue;
+        if (ev.det > 0 && ev.tScaled > lim) continue;
+        const float t = ev.tScaled * (1 / ev.det);
+        if (!(quirks & HRT_Q2_TRI_NO_TMIN) && t < t_min) continue;
+        t_max = t;
+        best = (int)ti;
+    }
+    t_out = t_max;
+    return best;
+}
+
 // ------------------------------------------------------------------ Mesh::hit -> BVHNode::hit (mesh.cpp:43-46, bvh.cpp:69-78)
 // Flattened 2-wide BVH walked by a RESUMABLE state machine: trav_step() advances one lane by one node or
 // one leaf, so the megakernel (bvh_traverse below) and the wavefront traversal kernel (which refills
@@ -661,6 +757,12 @@ __device__ inline int bvh_traverse(const DScene& sc, int mi /* mesh index */, ve
     float4 grid_o, grid_s;
     mesh_grid(sc, mi, grid_o, grid_s);
     const MeshRay r = mesh_ray_setup(o, d, quirks, grid_o, grid_s);
+    if (q4_risky(r.tr, d, quirks, sc.q4_route_a2)) {
+        const HRT_CONST_AS uint32_t* rm = uniform_table((const uint32_t*)sc.rmesh) + 4 * mi;
+        if (sc.ref_fold_all && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f)
+            return ref_fold<STATS>(sc.rtris + 3ull * rm[2], tbox, mesh.tri_count, o, d, r.tr, t_min, mesh_t_max(t_max), quirks, t_out, cnt);
+        return ref_walk<STATS>(sc.rnodes + 2ull * rm[0], sc.rtris + 3ull * rm[2], rm[1], o, d, r.tr, t_min, mesh_t_max(t_max), quirks, t_out, cnt);
+    }
     const float t_lo = trav_t_lo(t_min, quirks);
     TravState ts;
     trav_init(ts, mesh, mesh_t_max(t_max));

@@ -60,6 +60,10 @@ struct DeviceCounters {      // 64-bit accumulators in device memory
     unsigned long long trav_box_tests, trav_tri_tests;   // the share of box_tests / tri_tests counted inside k_wf_ext launches
 };
 
+// Number of set bits of a wave mask BELOW the calling lane (v_mbcnt_lo/hi: no per-lane 64-bit mask to keep in registers).
+__device__ inline unsigned lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ inline unsigned wave_sum(unsigned v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -250,6 +254,18 @@ struct WfBuf {
     float4* rad;                 // radiance of the finished path of each SLOT
     unsigned* live;              // per task: live paths, at positions [k*T, k*T + live[k])
     unsigned* qn;                // per task: rays queued for the current mesh
+    // Rays of quirk Q-4 that must walk the REFERENCE's tree (hrt_device.h q4_risky / ref_walk) are kept out of that queue:
+    // their records (E0..E2) go to the TOP of the task's segment, at (k+1)*T - 1 downwards, rn[k] of them (qn + rn <= live
+    // <= T, so the two never meet; the arrays are allocated to a whole number of tasks).
+    unsigned* rn;
+    // ... and the tasks that have such rays are listed for the traversal launch that will walk them: HRT_REF_GROUPS lists
+    // (task t goes to list t % HRT_REF_GROUPS, ref_cap entries each: {task, rn}); a launch's counter block holds the lists'
+    // lengths (words [0, 256)) and "next entry" counters (words [256, 512)).  ref_prod: the block of the launch the rays
+    // are prepared FOR (written by k_wf_gen / k_wf_pre / k_wf_shade), ref_cons: the block of this launch (k_wf_ext).
+    uint2* ref_list;
+    unsigned ref_cap;
+    unsigned* ref_prod;
+    unsigned* ref_cons;
     // Segment counts, one cell per k_wf_shade wave, folded into DeviceCounters::rays by k_wf_reduce: one atomic per
     // wave on the one counter costs 8192 same-address atomics = 93 us per launch (~88 per us, MI355X_MICROARCH
     // "dequeue"), which was the floor of every round of a small tile (one rank's share of an 8-GPU frame).
@@ -274,6 +290,7 @@ struct WfBuf {
 // there are -- the atomic's round trip is ~2 us, which is the whole cost of a late round's nearly empty task), and a wave
 // that can see it took the group's last task does not pull again to find out.
 #define HRT_TASK_GROUPS 251
+#define HRT_REF_GROUPS 251
 // With no more tasks than waves (small batches: one rank's share of a multi-GPU frame) every wave simply takes the task of
 // its own number (pull_k == 0): nothing to balance, and the atomic's round trip would be added to every launch.
 struct TaskPuller { unsigned wave, g, next, end; };   // wave-uniform; the rest lives in the kernel arguments (registers are dear)
@@ -340,11 +357,15 @@ __device__ inline rng_ctx slot_ctx(const hrt_params& pr, const RenderMap& map, u
 #define HRT_WAVE_FN __attribute__((always_inline)) inline
 // Preparation of one segment: analytic prims [p0, p1) in list order (closest-so-far semantics of
 // hittableList.cpp:12-19), then the ray in the space of mesh prim `mesh_prim` and the root-box filter.
+// Returns 0: nothing to traverse, 1: queue the ray for the culling traversal, 2: queue it for the walk of the reference's tree.
+#define HRT_ENQ_NONE 0
+#define HRT_ENQ_TRAVERSE 1
+#define HRT_ENQ_REFWALK 2
 template <bool STATS>
-__device__ HRT_WAVE_FN bool wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
+__device__ HRT_WAVE_FN int wf_prepare(const DScene& sc, const hrt_params& pr, int p0, int p1, int mesh_prim, vec3 o, vec3 d,
                                   const rng_ctx& ctx, float& closest, int& prim, int& sub, MeshRay& mr, unsigned& n_culled) {
     prims_range_hit(sc, p0, p1, o, d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
-    if (mesh_prim < 0) return false;
+    if (mesh_prim < 0) return HRT_ENQ_NONE;
     const auto& mp = uniform_table(sc.prims)[mesh_prim];
     const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
     vec3 lo = o, ld = d;
@@ -352,15 +373,42 @@ __device__ HRT_WAVE_FN bool wf_prepare(const DScene& sc, const hrt_params& pr, i
     float4 grid_o, grid_s;
     mesh_grid(sc, mp.mesh, grid_o, grid_s);
     mr = mesh_ray_setup(lo, ld, pr.quirks, grid_o, grid_s);
+    if (q4_risky(mr.tr, ld, pr.quirks, sc.q4_route_a2)) {
+        // the first step of the reference's walk, taken here: its root box (bvh.cpp:71) turns most of these rays away
+        const HRT_CONST_AS uint32_t* rm = uniform_table((const uint32_t*)sc.rmesh) + 4 * mp.mesh;
+        if (rm[1] == 0) return HRT_ENQ_NONE;
+        const HRT_CONST_AS float* rb = uniform_table((const float*)sc.rnodes) + 8ull * rm[0];
+        float4 bmn, bmx;
+        bmn.x = rb[0]; bmn.y = rb[1]; bmn.z = rb[2]; bmn.w = 0.0f; bmx.x = rb[4]; bmx.y = rb[5]; bmx.z = rb[6]; bmx.w = 0.0f;
+        return accept_box(bmn, bmx, lo, ld, pr.t_min, mesh_t_max(closest)) ? HRT_ENQ_REFWALK : HRT_ENQ_NONE;
+    }
     const bool enq = root_may_hit(sc, mesh, mr, trav_t_lo(pr.t_min, pr.quirks), mesh_t_max(closest));
     if (STATS && !enq && mesh.node_count) n_culled++;
-    return enq;
+    return enq ? HRT_ENQ_TRAVERSE : HRT_ENQ_NONE;
 }
 __device__ inline void wf_store_record(const WfBuf& w, unsigned q, const MeshRay& mr, float closest, unsigned pos) {
     w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, mesh_t_max(closest));   // what the traversal starts from: NaN -> +inf
     w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pos));
     w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
     w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, 0.0f);
+}
+// record of a ray for ref_walk: no culling constants
+__device__ inline void wf_store_ref_record(const WfBuf& w, unsigned q, const MeshRay& mr, float closest, unsigned pos) {
+    w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, mesh_t_max(closest));
+    w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pos));
+    w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
+}
+// Queues the lanes' rays of one 64-position chunk: kind 1 upwards from qpos, kind 2 downwards from rtop - rcount.
+__device__ HRT_WAVE_FN void wf_enqueue(const WfBuf& w, int kind, const MeshRay& mr, float closest, unsigned pos, unsigned long long lt,
+                                       unsigned& qpos, unsigned rtop, unsigned& rcount) {
+    const unsigned long long m = __ballot(kind == HRT_ENQ_TRAVERSE);
+    if (kind == HRT_ENQ_TRAVERSE) wf_store_record(w, qpos + lanes_below(m), mr, closest, pos);
+    qpos += (unsigned)__popcll(m);
+    const unsigned long long mr2 = __ballot(kind == HRT_ENQ_REFWALK);
+    if (mr2) {
+        if (kind == HRT_ENQ_REFWALK) wf_store_ref_record(w, rtop - rcount - lanes_below(mr2), mr, closest, pos);
+        rcount += (unsigned)__popcll(mr2);
+    }
 }
 __device__ inline void wf_store_state(const WfBuf& w, int par, unsigned pos, const PathState& ps, float closest, unsigned slot, int prim, int sub) {
     w.S0[par][pos] = make_float4(ps.o.x, ps.o.y, ps.o.z, closest);
@@ -369,6 +417,12 @@ __device__ inline void wf_store_state(const WfBuf& w, int par, unsigned pos, con
     w.S3[par][pos] = sub;
 }
 
+// A task's ref-walk rays are announced to the launch that will walk them (lane 0 of the wave that prepared them).
+__device__ inline void wf_ref_publish(const WfBuf& w, unsigned task, unsigned rcount) {
+    const unsigned g = task % HRT_REF_GROUPS;
+    const unsigned k = atomicAdd(&w.ref_prod[g], 1u);
+    w.ref_list[(size_t)g * w.ref_cap + k] = make_uint2(task, rcount);
+}
 // Camera rays (main.cpp:115-123) of every slot of the batch + the preparation of their first segment.
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_params pr, RenderMap map, WfScene ws, unsigned n_local, int s0,
@@ -380,10 +434,10 @@ __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_p
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
         const unsigned base = task * w.T;
         const unsigned n = base < n_slots ? min(w.T, n_slots - base) : 0u;
-        unsigned qpos = base;
+        unsigned qpos = base, rcount = 0;
         for (unsigned j0 = 0; j0 < n; j0 += 64) {
             const unsigned j = j0 + lane;
-            bool enq = false;
+            int enq = HRT_ENQ_NONE;
             MeshRay mr;
             float closest = __builtin_huge_valf();
             const unsigned slot = base + j;
@@ -399,11 +453,9 @@ __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_p
                 enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
                 wf_store_state(w, 0, slot, ps, closest, slot, prim, sub);
             }
-            const unsigned long long m = __ballot(enq);
-            if (enq) wf_store_record(w, qpos + (unsigned)__popcll(m & lt), mr, closest, slot);
-            qpos += (unsigned)__popcll(m);
+            wf_enqueue(w, enq, mr, closest, slot, lt, qpos, base + w.T - 1, rcount);
         }
-        if (lane == 0) { w.live[task] = n; w.qn[task] = qpos - base; }
+        if (lane == 0) { w.live[task] = n; w.qn[task] = qpos - base; w.rn[task] = rcount; if (rcount) wf_ref_publish(w, task, rcount); }
     }
     if (STATS) {
         const unsigned c = wave_sum(n_culled);
@@ -419,12 +471,12 @@ __global__ __launch_bounds__(256) void k_wf_gen(DScene sc, hrt_camera cam, hrt_p
 template <bool STATS>
 __device__ HRT_WAVE_FN unsigned wf_pre_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, unsigned n_local, int s0, int round, int par,
                                        int p0, int mesh_prim, const WfBuf& w, unsigned task, unsigned n, unsigned lane, unsigned long long lt,
-                                       unsigned& n_culled) {
+                                       unsigned& n_culled, unsigned& rn_out) {
     const unsigned base = task * w.T;
-    unsigned qpos = base;
+    unsigned qpos = base, rcount = 0;
     for (unsigned j0 = 0; j0 < n; j0 += 64) {
         const unsigned pos = base + j0 + lane;
-        bool enq = false;
+        int enq = HRT_ENQ_NONE;
         MeshRay mr;
         float closest = 0.0f;
         if (j0 + lane < n) {
@@ -441,10 +493,9 @@ __device__ HRT_WAVE_FN unsigned wf_pre_task(const DScene& sc, const hrt_params& 
                 w.S3[par][pos] = sub;
             }
         }
-        const unsigned long long m = __ballot(enq);
-        if (enq) wf_store_record(w, qpos + (unsigned)__popcll(m & lt), mr, closest, pos);
-        qpos += (unsigned)__popcll(m);
+        wf_enqueue(w, enq, mr, closest, pos, lt, qpos, base + w.T - 1, rcount);
     }
+    rn_out = rcount;
     return qpos - base;
 }
 template <bool STATS>
@@ -455,8 +506,9 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned n_culled = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        const unsigned qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, round, par, p0, mesh_prim, w, task, HRT_UNIFORM(w.live[task]), lane, lt, n_culled);
-        if (lane == 0) w.qn[task] = qn;
+        unsigned rn;
+        const unsigned qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, round, par, p0, mesh_prim, w, task, HRT_UNIFORM(w.live[task]), lane, lt, n_culled, rn);
+        if (lane == 0) { w.qn[task] = qn; w.rn[task] = rn; if (rn) wf_ref_publish(w, task, rn); }
     }
     if (STATS) {
         const unsigned c = wave_sum(n_culled);
@@ -486,6 +538,218 @@ __device__ inline ExtMesh wf_ext_mesh(const DScene& sc, int mesh_prim) {
     m.node_count = mesh.node_count;
     return m;
 }
+struct RefMesh { const uint4* nodes; const float4* tris; const float4* tbox; uint32_t node_count, tri_count; };   // the same for the reference-tree walks
+__device__ inline RefMesh wf_ref_mesh(const DScene& sc, int mesh_prim) {
+    RefMesh m;
+    const auto& mp = uniform_table(sc.prims)[mesh_prim];
+    const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
+    const HRT_CONST_AS uint32_t* rm = uniform_table((const uint32_t*)sc.rmesh) + 4 * mp.mesh;
+    m.nodes = sc.rnodes + 2ull * rm[0]; m.tris = sc.rtris + 3ull * rm[2]; m.node_count = rm[1];
+    m.tbox = sc.tri_box + 2ull * mesh.tri_first; m.tri_count = mesh.tri_count;
+    return m;
+}
+__device__ inline void wf_store_hit(const WfBuf& w, int par, unsigned pos, int mesh_prim, int tri, float t) {
+    ((float*)&w.S0[par][pos])[3] = t;
+    ((float*)&w.S2[par][pos])[3] = __int_as_float(mesh_prim);
+    w.S3[par][pos] = tri;
+}
+// One LANE walks the reference's tree for the ray of record q (ref_walk: node by node, verbatim) and stores a hit like wf_ext_run does.
+template <bool STATS>
+__device__ HRT_WAVE_FN void wf_ref_one(const RefMesh& rm, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, unsigned q, DCounters& cnt) {
+    const float4 e0 = w.E0[q], e1 = w.E1[q], e2 = w.E2[q];
+    TriRay tr;
+    const vec3 o(e0.x, e0.y, e0.z), d(e1.x, e1.y, e1.z);
+    tr.o = o; tr.sX = e2.x; tr.sY = e2.y; tr.sZ = e2.z; tr.kZ = __float_as_int(e2.w);
+    float t;
+    const int tri = ref_walk<STATS>(rm.nodes, rm.tris, rm.node_count, o, d, tr, pr.t_min, e0.w, pr.quirks, t, cnt);
+    if (tri >= 0) wf_store_hit(w, par, __float_as_uint(e1.w), mesh_prim, tri, t);
+}
+// One WAVE does the same for up to HRT_BFS_RAYS rays at once, breadth first.  A lane's walk is a chain of ~250 dependent
+// node fetches, ~1 us each once the shading kernels' streams have swept the L2: longer than a late round's whole traversal
+// launch, and every one of the 50 rounds waits for it.  What the walk computes is a FOLD over the triangles in the tree's
+// depth-first order: a triangle that passes the t_max-independent part of ITriangle::hit (edge functions, determinant,
+// sign of tScaled: triangle.cpp:98-105) is met with the t_max of that moment, is reached if the boxes above it let it
+// through (bvh.cpp:71), and then shrinks t_max (bvh.cpp:75).  Of those boxes only the LOWEST can fail on account of
+// t_max: a box is the exact union of what is below it and IEEE - and / are monotone, so a higher box's slab interval
+// contains the lowest one's, and t_max only shrinks on the way down (up to the last-bit play of triangle.cpp:106-109).
+// So: (1) the wave walks the tree level by level with the ray's initial t_max -- every (ray, node) pair of a level is one
+// lane's box test, a level costs one fetch latency whatever its width, ~13 levels for the teapot -- and collects the
+// candidate triangles; (2) lane r folds ray r's candidates in depth-first order, with the lowest node's box test (aabb.h:
+// 26-39 as written: accept_box) done once per node with the t_max at the node's first candidate, and triangle.cpp:106-109
+// as written.  The pairs live in the wave's share of the LDS traversal stack (`sb`, `words` of them), which is idle here.
+// Rays with an exactly zero direction component (0/0 slabs are not monotone), and all rays of a group whose level or
+// candidate list outgrows the LDS, take the lane's walk instead.
+#define HRT_BFS_RAYS 8
+#define HRT_BFS_CANDS 64
+__device__ inline int& wave_lds(int* sb, unsigned i) { return sb[(i >> 6) * HRT_BLOCK + (i & 63u)]; }   // word i of the wave's share of stack[depth][256]
+template <bool STATS>
+__device__ HRT_WAVE_FN void wf_ref_bfs(const RefMesh& rm, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, unsigned n, unsigned q_mine,
+                                       int* sb, unsigned words, unsigned lane, DCounters& cnt) {
+    const unsigned off_cand = HRT_BFS_RAYS * 12u, off_f0 = off_cand + HRT_BFS_CANDS;
+    const unsigned fcap = (words - off_f0) / 2u;
+    const bool mine = lane < n;
+    float4 e0 = make_float4(0, 0, 0, 0), e1 = e0, e2 = e0;
+    bool alone = false;
+    if (mine) {
+        e0 = w.E0[q_mine]; e1 = w.E1[q_mine]; e2 = w.E2[q_mine];
+        alone = e1.x == 0.0f || e1.y == 0.0f || e1.z == 0.0f || rm.node_count >= (1u << 26);
+        const unsigned b = lane * 12u;
+        wave_lds(sb, b + 0) = __float_as_int(e0.x); wave_lds(sb, b + 1) = __float_as_int(e0.y); wave_lds(sb, b + 2) = __float_as_int(e0.z);
+        wave_lds(sb, b + 3) = __float_as_int(e1.x); wave_lds(sb, b + 4) = __float_as_int(e1.y); wave_lds(sb, b + 5) = __float_as_int(e1.z);
+        wave_lds(sb, b + 6) = __float_as_int(e2.x); wave_lds(sb, b + 7) = __float_as_int(e2.y); wave_lds(sb, b + 8) = __float_as_int(e2.z);
+        wave_lds(sb, b + 9) = __float_as_int(e2.w);
+        // t_max for the level walk: what an accepted t can exceed the t_max it was compared with (a few ulp per candidate)
+        wave_lds(sb, b + 10) = __float_as_int(e0.w + fabsf(e0.w) * 2e-6f);
+    }
+    unsigned cur = off_f0, nxt = off_f0 + fcap, n_cur, n_cand = 0;
+    {
+        const bool go = mine && !alone;
+        const unsigned long long m = __ballot(go);
+        if (go) wave_lds(sb, cur + lanes_below(m)) = (int)(lane << 26);            // (ray, root)
+        n_cur = (unsigned)__popcll(m);
+    }
+    bool overflow = false;
+    while (n_cur && !overflow) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned n_next = 0;
+        for (unsigned b = 0; b < n_cur && !overflow; b += 64) {
+            const bool valid = b + lane < n_cur;
+            unsigned r = 0, node = 0;
+            bool pass = false;
+            uint4 B; B.x = B.y = B.z = B.w = 0;
+            vec3 o, d;
+            if (valid) {
+                const unsigned item = (unsigned)wave_lds(sb, cur + b + lane);
+                r = item >> 26; node = item & 0x3ffffffu;
+                const uint4 A = rm.nodes[2 * node];
+                B = rm.nodes[2 * node + 1];
+                const unsigned rb = r * 12u;
+                o = vec3(__int_as_float(wave_lds(sb, rb + 0)), __int_as_float(wave_lds(sb, rb + 1)), __int_as_float(wave_lds(sb, rb + 2)));
+                d = vec3(__int_as_float(wave_lds(sb, rb + 3)), __int_as_float(wave_lds(sb, rb + 4)), __int_as_float(wave_lds(sb, rb + 5)));
+                float4 bmn, bmx;
+                bmn.x = __uint_as_float(A.x); bmn.y = __uint_as_float(A.y); bmn.z = __uint_as_float(A.z); bmn.w = 0.0f;
+                bmx.x = __uint_as_float(B.x); bmx.y = __uint_as_float(B.y); bmx.z = __uint_as_float(B.z); bmx.w = 0.0f;
+                pass = accept_box(bmn, bmx, o, d, pr.t_min, __int_as_float(wave_lds(sb, rb + 10)));
+            }
+            const bool inner = pass && (B.w & 0x80000000u);
+            const unsigned long long mi = __ballot(inner);
+            const unsigned n_in = (unsigned)__popcll(mi);
+            if (n_next + 2u * n_in > fcap) { overflow = true; break; }
+            if (inner) {
+                const unsigned k = nxt + n_next + 2u * lanes_below(mi);
+                wave_lds(sb, k) = (int)((r << 26) | (node + 1u));                         // left = the next node (bvh.cpp:74)
+                wave_lds(sb, k + 1u) = (int)((r << 26) | (B.w & 0x3ffffffu));             // right
+            }
+            n_next += 2u * n_in;
+            const bool leaf = pass && !inner;
+            if (__ballot(leaf)) {
+                TriRay tr;
+                if (leaf) {
+                    const unsigned rb = r * 12u;
+                    tr.o = o; tr.sX = __int_as_float(wave_lds(sb, rb + 6)); tr.sY = __int_as_float(wave_lds(sb, rb + 7)); tr.sZ = __int_as_float(wave_lds(sb, rb + 8));
+                    tr.kZ = wave_lds(sb, rb + 9);
+                }
+                for (unsigned k = 0; k < 2u; ++k) {
+                    const unsigned p = (B.w >> 1) + k;
+                    bool cand = false;
+                    if (leaf && k <= (B.w & 1u)) {
+                        const float4 q0 = rm.tris[3 * p + 0], q1 = rm.tris[3 * p + 1], q2 = rm.tris[3 * p + 2];
+                        TriEval ev;
+                        if (tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev))
+                            cand = !((ev.det < 0 && ev.tScaled >= 0) || (ev.det > 0 && ev.tScaled <= 0));
+                    }
+                    const unsigned long long mc = __ballot(cand);
+                    if (n_cand + (unsigned)__popcll(mc) > HRT_BFS_CANDS) { overflow = true; break; }
+                    if (cand) wave_lds(sb, off_cand + n_cand + lanes_below(mc)) = (int)((r << 28) | p);
+                    n_cand += (unsigned)__popcll(mc);
+                }
+            }
+        }
+        const unsigned t = cur; cur = nxt; nxt = t;
+        n_cur = n_next;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (!mine) return;
+    if (alone || overflow) { wf_ref_one<STATS>(rm, pr, mesh_prim, par, w, q_mine, cnt); return; }
+    // (2) the fold over this lane's candidates in depth-first order
+    TriRay tr;
+    const vec3 o(e0.x, e0.y, e0.z), d(e1.x, e1.y, e1.z);
+    tr.o = o; tr.sX = e2.x; tr.sY = e2.y; tr.sZ = e2.z; tr.kZ = __float_as_int(e2.w);
+    float t_max = e0.w;
+    int best = -1, last = -1;
+    unsigned cur_node = 0xffffffffu;
+    bool node_ok = false;
+    for (;;) {
+        unsigned p = 0xffffffffu;
+        for (unsigned j = 0; j < n_cand; ++j) {
+            const unsigned c = (unsigned)wave_lds(sb, off_cand + j);
+            if ((c >> 28) == lane && (int)(c & 0xfffffffu) > last && (c & 0xfffffffu) < p) p = c & 0xfffffffu;
+        }
+        if (p == 0xffffffffu) break;
+        last = (int)p;
+        const float4 q0 = rm.tris[3 * p + 0], q1 = rm.tris[3 * p + 1], q2 = rm.tris[3 * p + 2];
+        TriEval ev;
+        if (!tri_eval(tr, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), ev)) continue;   // (cannot happen: it passed above)
+        const unsigned ti = __float_as_uint(q0.w);
+        const float4 bmn = rm.tbox[2 * ti], bmx = rm.tbox[2 * ti + 1];
+        const unsigned node = __float_as_uint(bmn.w) >> 1;
+        if (node != cur_node) { cur_node = node; node_ok = accept_box(bmn, bmx, o, d, pr.t_min, t_max); }
+        if (!node_ok) continue;
+        const float lim = t_max * ev.det;                                    // triangle.cpp:106-109
+        if (ev.det < 0 && ev.tScaled < lim) continue;
+        if (ev.det > 0 && ev.tScaled > lim) continue;
+        const float t = ev.tScaled * (1 / ev.det);
+        if (!(pr.quirks & HRT_Q2_TRI_NO_TMIN) && t < pr.t_min) continue;
+        t_max = t;
+        best = (int)ti;
+    }
+    if (best >= 0) wf_store_hit(w, par, __float_as_uint(e1.w), mesh_prim, best, t_max);
+}
+// The ref-walk rays of ONE task (k_wf_tail: by the wave that owns the task), HRT_BFS_RAYS at a time.
+template <bool STATS>
+__device__ HRT_WAVE_FN void wf_ref_task(const RefMesh& rm, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, unsigned task, unsigned rn,
+                                        int* sb, unsigned words, unsigned lane, DCounters& cnt) {
+    const unsigned top = (task + 1u) * w.T - 1u;
+    for (unsigned done = 0; done < rn; done += HRT_BFS_RAYS) {
+        const unsigned n = rn - done < HRT_BFS_RAYS ? rn - done : HRT_BFS_RAYS;
+        wf_ref_bfs<STATS>(rm, pr, mesh_prim, par, w, n, top - (done + (lane < n ? lane : 0u)), sb, words, lane, cnt);
+    }
+}
+// The ref-walk rays of ALL tasks, inside the k_wf_ext launch (beside the culling traversal, not after it: a launch of their
+// own would add its latency to each of the 50 rounds), by every wave BEFORE it turns to its traversal tasks: in the early
+// rounds these rays are 5 % of the launch's work, and since tasks are pulled dynamically the waves that walked some simply
+// traverse less; in the late rounds the handful there is starts at once.  Wave w serves the lists w, w + waves, ... (mod
+// HRT_REF_GROUPS; ~24 waves per list) and pulls one {task, rn} entry at a time until HRT_BFS_RAYS rays are together.  A wave
+// looks before it pulls (plain loads of the list's length and counter): same-address atomics retire at ~88 per us.
+template <bool STATS>
+__device__ HRT_WAVE_FN void wf_ref_consume(const RefMesh& rm, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, unsigned wave, unsigned n_waves,
+                                           int* sb, unsigned words, unsigned lane, DCounters& cnt) {
+    for (unsigned g = wave % HRT_REF_GROUPS; g < HRT_REF_GROUPS; g += (n_waves < HRT_REF_GROUPS ? n_waves : HRT_REF_GROUPS)) {
+        const unsigned len = HRT_UNIFORM(w.ref_cons[g]);
+        if (len == 0 || HRT_UNIFORM(__atomic_load_n(&w.ref_cons[256 + g], __ATOMIC_RELAXED)) >= len) continue;
+        unsigned top = 0, next = 0, end = 0;       // the entry being handed out: rays [next, end) at records top - i
+        bool dry = false;
+        for (;;) {
+            unsigned have = 0, q = 0;
+            while (have < HRT_BFS_RAYS) {
+                if (next >= end) {
+                    if (dry) break;
+                    unsigned k = 0;
+                    if (lane == 0) k = atomicAdd(&w.ref_cons[256 + g], 1u);
+                    k = HRT_UNIFORM(k);
+                    if (k >= len) { dry = true; break; }
+                    const uint2 e = w.ref_list[(size_t)g * w.ref_cap + k];
+                    top = (HRT_UNIFORM(e.x) + 1u) * w.T - 1u; next = 0; end = HRT_UNIFORM(e.y);
+                }
+                const unsigned take = end - next < HRT_BFS_RAYS - have ? end - next : HRT_BFS_RAYS - have;
+                if (lane >= have && lane < have + take) q = top - (next + (lane - have));
+                have += take; next += take;
+            }
+            if (!have) break;
+            wf_ref_bfs<STATS>(rm, pr, mesh_prim, par, w, have, q, sb, words, lane, cnt);
+        }
+    }
+}
 template <bool STATS, class NextRange>
 __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, int* stack, unsigned lane,
                                   unsigned long long lt, int leaf_num, DCounters& cnt, NextRange next_range) {
@@ -503,7 +767,7 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
             while (cur_pos >= cur_end && !wave_done)
                 if (!next_range(cur_pos, cur_end)) wave_done = true;
             if (!wave_done) {
-                const unsigned q = cur_pos + (unsigned)__popcll(need & lt);
+                const unsigned q = cur_pos + lanes_below(need);
                 if (!has && q < cur_end) {
                     const float4 e0 = w.E0[q], e1 = w.E1[q], e2 = w.E2[q], e3 = w.E3[q];
                     r.o = vec3(e0.x, e0.y, e0.z); r.d = vec3(e1.x, e1.y, e1.z);
@@ -556,15 +820,20 @@ __global__ __launch_bounds__(HRT_BLOCK) __attribute__((amdgpu_waves_per_eu(DEPTH
     __shared__ int s_stack[DEPTH * HRT_BLOCK];
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const ExtMesh em = wf_ext_mesh(sc, mesh_prim);
-    TaskPuller puller = HRT_TASK_PULLER((blockIdx.x * blockDim.x + threadIdx.x) >> 6, w.n_groups);
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
-    wf_ext_run<STATS>(em, pr, mesh_prim, par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
-        unsigned t;
-        if (!wf_next_task(w, puller, lane, t)) return false;
-        first = t * w.T; end = first + HRT_UNIFORM(w.qn[t]);
-        return true;
-    });
+    const unsigned wave = HRT_UNIFORM((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (pr.quirks & HRT_Q4_SHEAR_FROM_ORIGIN)
+        wf_ref_consume<STATS>(wf_ref_mesh(sc, mesh_prim), pr, mesh_prim, par, w, wave, (gridDim.x * blockDim.x) >> 6, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
+    {
+        const ExtMesh em = wf_ext_mesh(sc, mesh_prim);
+        TaskPuller puller = HRT_TASK_PULLER(wave, w.n_groups);
+        wf_ext_run<STATS>(em, pr, mesh_prim, par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
+            unsigned t;
+            if (!wf_next_task(w, puller, lane, t)) return false;
+            first = t * w.T; end = first + HRT_UNIFORM(w.qn[t]);
+            return true;
+        });
+    }
     if (STATS) {
         const unsigned bt = wave_sum(cnt.box_tests), tt = wave_sum(cnt.tri_tests);
         if (lane == 0) {
@@ -607,10 +876,10 @@ __device__ inline void missq_flush(const DScene& sc, const WfBuf& w, MissQueue& 
 template <bool STATS>
 __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr, const RenderMap& map, const WfScene& ws, unsigned n_local, int s0, int round,
                                      const WfBuf& w, unsigned task, unsigned n, unsigned lane, unsigned long long lt, MissQueue& mq,
-                                     PathCounters& pc, unsigned& n_seg, unsigned& n_culled, unsigned& live_out, unsigned& qn_out) {
+                                     PathCounters& pc, unsigned& n_seg, unsigned& n_culled, unsigned& live_out, unsigned& qn_out, unsigned& rn_out) {
     const int par = round & 1, nxt = par ^ 1;
     const unsigned base = task * w.T;
-    unsigned out = base, qpos = base;
+    unsigned out = base, qpos = base, rcount = 0;
     for (unsigned j0 = 0; j0 < n; j0 += 64) {
         const unsigned pos = base + j0 + lane;
         float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
@@ -638,7 +907,7 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
             const unsigned long long mm = __ballot(missed);
             if (mm) {
                 if (missed) {
-                    const unsigned e = mq.count + (unsigned)__popcll(mm & lt);
+                    const unsigned e = mq.count + lanes_below(mm);
                     mq.f[0 * HRT_MISSQ_CAP + e] = ps.d.x; mq.f[1 * HRT_MISSQ_CAP + e] = ps.d.y; mq.f[2 * HRT_MISSQ_CAP + e] = ps.d.z;
                     mq.f[3 * HRT_MISSQ_CAP + e] = ps.atten.x; mq.f[4 * HRT_MISSQ_CAP + e] = ps.atten.y; mq.f[5 * HRT_MISSQ_CAP + e] = ps.atten.z;
                     mq.slot[e] = slot;
@@ -661,23 +930,21 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
             }
         }
         const unsigned long long ma = __ballot(alive);
-        bool enq = false;
+        int enq = HRT_ENQ_NONE;
         MeshRay mr;
         float closest = __builtin_huge_valf();
         unsigned npos = 0;
         if (alive) {
-            npos = out + (unsigned)__popcll(ma & lt);
+            npos = out + lanes_below(ma);
             int prim = -1, sub = -1;
             ctx.bounce = (uint32_t)(round + 1);   // the next segment's draws (ConstantMedium::hit inside wf_prepare)
             enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
             wf_store_state(w, nxt, npos, ps, closest, slot, prim, sub);
         }
         out += (unsigned)__popcll(ma);
-        const unsigned long long me = __ballot(enq);
-        if (enq) wf_store_record(w, qpos + (unsigned)__popcll(me & lt), mr, closest, npos);
-        qpos += (unsigned)__popcll(me);
+        wf_enqueue(w, enq, mr, closest, npos, lt, qpos, base + w.T - 1, rcount);
     }
-    live_out = out - base; qn_out = qpos - base;
+    live_out = out - base; qn_out = qpos - base; rn_out = rcount;
 }
 // what a shading wave adds to the device counters when it is done
 template <bool STATS>
@@ -711,9 +978,9 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     unsigned n_seg = 0, n_culled = 0;
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        unsigned live, qn;
-        wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, round, w, task, HRT_UNIFORM(w.live[task]), lane, lt, mq, pc, n_seg, n_culled, live, qn);
-        if (lane == 0) { w.live[task] = live; w.qn[task] = qn; }
+        unsigned live, qn, rn;
+        wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, round, w, task, HRT_UNIFORM(w.live[task]), lane, lt, mq, pc, n_seg, n_culled, live, qn, rn);
+        if (lane == 0) { w.live[task] = live; w.qn[task] = qn; w.rn[task] = rn; if (rn) wf_ref_publish(w, task, rn); }
     }
     if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
     wf_shade_counters<STATS>(w, counters, wave, lane, n_seg, n_culled, pc);
@@ -745,12 +1012,16 @@ __global__ __launch_bounds__(256, 2) void k_wf_tail(DScene sc, hrt_params pr, Re
     PathCounters pc; pc.rays = 0; pc.samples = 0; pc.mesh_hits = 0; pc.env_lookups = 0; pc.bvh.box_tests = 0; pc.bvh.tri_tests = 0;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
     HRT_FOR_MY_TASKS(task, w, wave, lane) {
-        unsigned live = HRT_UNIFORM(w.live[task]), qn = HRT_UNIFORM(w.qn[task]);     // as the last per-round launches left them
+        unsigned live = HRT_UNIFORM(w.live[task]), qn = HRT_UNIFORM(w.qn[task]), rn = HRT_UNIFORM(w.rn[task]);     // as the last per-round launches left them
         for (int r = round0; r < rounds_end && live; ++r) {
             const int par = r & 1;
             for (int m = 0; m < tm.n; ++m) {
                 if (m > 0) {
-                    qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, r, par, tm.prim[m - 1] + 1, tm.prim[m], w, task, live, lane, lt, n_culled);
+                    qn = wf_pre_task<STATS>(sc, pr, map, n_local, s0, r, par, tm.prim[m - 1] + 1, tm.prim[m], w, task, live, lane, lt, n_culled, rn);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                }
+                if (rn) {
+                    wf_ref_task<STATS>(wf_ref_mesh(sc, tm.prim[m]), pr, tm.prim[m], par, w, task, rn, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 }
                 if (qn) {
@@ -765,10 +1036,10 @@ __global__ __launch_bounds__(256, 2) void k_wf_tail(DScene sc, hrt_params pr, Re
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 }
             }
-            wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, r, w, task, live, lane, lt, mq, pc, n_seg, n_culled, live, qn);
+            wf_shade_task<STATS>(sc, pr, map, ws, n_local, s0, r, w, task, live, lane, lt, mq, pc, n_seg, n_culled, live, qn, rn);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
-        if (lane == 0) { w.live[task] = live; w.qn[task] = qn; }
+        if (lane == 0) { w.live[task] = live; w.qn[task] = qn; w.rn[task] = rn; }
     }
     if (mq.count) missq_flush<STATS>(sc, w, mq, lane, mq.count, pc);
     wf_shade_counters<STATS>(w, counters, wave, lane, n_seg, n_culled, pc);
@@ -1043,6 +1314,8 @@ size_t wf_max_slots(const hrt_scene* sc) {
 
 // "next task" counters: one block of 256 words per kernel launch of a batch (gen + per round: ext and pre per mesh, shade)
 size_t wf_counter_words(int depth, int n_mesh) { return (size_t)256 * (2 + (size_t)depth * (2 * (size_t)std::max(1, n_mesh) + 1)); }
+// ... and of 512 words per traversal launch for its ref-walk lists (WfBuf::ref_prod / ref_cons), + one block nobody reads
+size_t wf_ref_counter_words(int depth, int n_mesh) { return (size_t)512 * ((size_t)depth * (size_t)std::max(1, n_mesh) + 1); }
 
 hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     WfWorkspace& w = sc->wf;
@@ -1051,10 +1324,11 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     if (w.base) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(w.base); w = WfWorkspace(); }
     const size_t max_tasks = slots / 64 + 1;   // the smallest task HRT_WF_TASK_SIZE can ask for is 64 positions (the default is >= 256)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t f4 = al(slots * sizeof(float4));
-    const size_t i4 = al(slots * sizeof(int));
-    const size_t ctr_words = wf_counter_words(depth, n_mesh);
-    const size_t total = 11 * f4 + 2 * i4 + 2 * al(max_tasks * sizeof(unsigned)) + al(ctr_words * sizeof(unsigned)) +
+    const size_t f4 = al((slots + 4096) * sizeof(float4));   // to a whole number of tasks (T <= 4096): ref-walk records sit at the top of a task's segment
+    const size_t i4 = al((slots + 4096) * sizeof(int));
+    const size_t ctr_words = wf_counter_words(depth, n_mesh) + wf_ref_counter_words(depth, n_mesh);
+    const size_t ref_cap = max_tasks / HRT_REF_GROUPS + 1;
+    const size_t total = 11 * f4 + 2 * i4 + 3 * al(max_tasks * sizeof(unsigned)) + al(ctr_words * sizeof(unsigned)) + al(ref_cap * HRT_REF_GROUPS * sizeof(uint2)) +
                          al((size_t)sc->n_cus * 32 * sizeof(unsigned long long));                                      // 184 B per slot
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, total);
@@ -1068,7 +1342,10 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     w.buf.rad = (float4*)take(f4);
     w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
+    w.buf.rn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.task_ctr = (unsigned*)take(al(ctr_words * sizeof(unsigned)));
+    w.buf.ref_list = (uint2*)take(al(ref_cap * HRT_REF_GROUPS * sizeof(uint2)));
+    w.buf.ref_cap = (unsigned)ref_cap;
     w.buf.n_wave_rays = (unsigned)sc->n_cus * 8u * 4u;           // k_wf_shade never runs more waves (task_blocks <= 8 per CU, 4 waves each)
     w.buf.wave_rays = (unsigned long long*)take(al((size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
     HIPCHK(hipMemset(w.buf.wave_rays, 0, (size_t)w.buf.n_wave_rays * sizeof(unsigned long long)));
@@ -1136,7 +1413,11 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
         // every launch of the batch gets its own zeroed block of "next task" counters
         unsigned* const ctr_base = sc->wf.buf.task_ctr;
-        HIPCHK(hipMemsetAsync(ctr_base, 0, wf_counter_words(D, n_mesh) * sizeof(unsigned), stream));
+        HIPCHK(hipMemsetAsync(ctr_base, 0, (wf_counter_words(D, n_mesh) + wf_ref_counter_words(D, n_mesh)) * sizeof(unsigned), stream));
+        // ref-walk list counters: block (r, m) belongs to the traversal launch of round r, mesh m; the last block is a sink
+        unsigned* const ref_base = ctr_base + wf_counter_words(D, n_mesh);
+        const int nm1 = std::max(1, n_mesh);
+        auto ref_block = [&](int r, int m) { return ref_base + 512 * (size_t)((r < D && m < nm1) ? r * nm1 + m : D * nm1); };
         size_t launch_no = 0;
         const bool force_dynamic = getenv("HRT_WF_DYNAMIC_TASKS") != nullptr;   // tests: exercise the pull path on small tiles too
         auto next_counters = [&](unsigned waves) {
@@ -1146,6 +1427,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
             w.group_q = w.n_tasks / w.n_groups; w.group_r = w.n_tasks % w.n_groups;
         };
         next_counters((unsigned)task_blocks * 4u);
+        w.ref_prod = ref_block(0, 0); w.ref_cons = ref_block(D, 0);
         if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         else hipLaunchKernelGGL(k_wf_gen<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *cam, *pr, map, ws, n_local, s0, n_slots, w, sc->d_counters);
         for (int r = 0; r < tail_round; ++r) {
@@ -1155,6 +1437,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 if (m > 0) {   // further meshes: analytic prims between the meshes + preparation
                     const int p0 = sc->mesh_prims[m - 1] + 1;
                     next_counters((unsigned)task_blocks * 4u);
+                    w.ref_prod = ref_block(r, m); w.ref_cons = ref_block(D, 0);
                     if (stats) hipLaunchKernelGGL(k_wf_pre<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
                     else hipLaunchKernelGGL(k_wf_pre<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, n_local, s0, r, par, p0, mp, w, sc->d_counters);
                 }
@@ -1165,6 +1448,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 const int variant = md <= 20 ? 20 : (md <= 24 ? 24 : 32);
                 const int ext_blocks = sc->n_cus * (ext_per_cu_env ? ext_per_cu_env : (variant == 32 ? 4 : 6));
                 next_counters((unsigned)ext_blocks * (HRT_BLOCK / 64));
+                w.ref_prod = ref_block(D, 0); w.ref_cons = ref_block(r, m);
 #define HRT_LAUNCH_EXT(S, D) hipLaunchKernelGGL((k_wf_ext<S, D>), dim3(ext_blocks), dim3(HRT_BLOCK), 0, stream, sc->ds, *pr, mp, par, w, sc->d_counters, leaf_num)
                 if (stats) { if (variant == 20) HRT_LAUNCH_EXT(true, 20); else if (variant == 24) HRT_LAUNCH_EXT(true, 24); else HRT_LAUNCH_EXT(true, 32); }
                 else { if (variant == 20) HRT_LAUNCH_EXT(false, 20); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
@@ -1172,6 +1456,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
             }
             next_counters((unsigned)task_blocks * 4u);
+            w.ref_prod = ref_block(r + 1, 0); w.ref_cons = ref_block(D, 0);
             if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
             else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
         }
@@ -1183,6 +1468,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
             const int variant = need <= 20 ? 20 : (need <= 24 ? 24 : 32);
             const int tail_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * (variant == 32 ? 2 : 3));   // 46..58 KB of LDS per block
             next_counters((unsigned)tail_blocks * 4u);
+            w.ref_prod = ref_block(D, 0); w.ref_cons = ref_block(D, 0);
 #define HRT_LAUNCH_TAIL(S, DP) hipLaunchKernelGGL((k_wf_tail<S, DP>), dim3(tail_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, tm, n_local, s0, tail_round, D, w, sc->d_counters, leaf_num)
             if (stats) { if (variant == 20) HRT_LAUNCH_TAIL(true, 20); else if (variant == 24) HRT_LAUNCH_TAIL(true, 24); else HRT_LAUNCH_TAIL(true, 32); }
             else { if (variant == 20) HRT_LAUNCH_TAIL(false, 20); else if (variant == 24) HRT_LAUNCH_TAIL(false, 24); else HRT_LAUNCH_TAIL(false, 32); }
@@ -1325,8 +1611,18 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     uint4* d_nodes; float4* d_grids;
     UP(d_nodes, qn.data(), qn.size() * sizeof(uint32_t));
     UP(d_grids, grids.data(), grids.size() * sizeof(float));
+    // the reference's own tree of every mesh, for the rays that must walk it (hrt_device.h ref_walk)
+    RefTree ref;
+    {
+        std::string why;
+        if (!pack_ref_tree(f, ref, &why)) { hrt_scene_destroy(sc); return fail(HRT_ERR_INVALID, why); }
+    }
+    uint4 *d_rnodes, *d_rmesh; float4* d_rtris;
+    UP(d_rnodes, ref.nodes.data(), ref.nodes.size() * sizeof(uint32_t));
+    UP(d_rtris, ref.tris.data(), ref.tris.size() * sizeof(float));
+    UP(d_rmesh, ref.mesh_nodes.data(), ref.mesh_nodes.size() * sizeof(uint32_t));
     std::vector<float> pos, attr, box;
-    pack_triangles(f, pos, attr, box);
+    pack_triangles(f, ref, pos, attr, box);
     float4 *d_pos, *d_attr, *d_box;
     UP(d_pos, pos.data(), pos.size() * sizeof(float));
     UP(d_attr, attr.data(), attr.size() * sizeof(float));
@@ -1342,6 +1638,13 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
 
     sc->ds.prims = d_prims; sc->ds.mats = d_mats; sc->ds.texs = d_texs; sc->ds.meshes = d_meshes;
     sc->ds.qnodes = d_nodes; sc->ds.grids = d_grids; sc->ds.tri_pos = d_pos; sc->ds.tri_attr = d_attr; sc->ds.tri_box = d_box;
+    sc->ds.rnodes = d_rnodes; sc->ds.rtris = d_rtris; sc->ds.rmesh = d_rmesh;
+    {   // experiments: the shear amplification |d| / |d[kZ]| from which a Q-4 ray walks the reference's tree
+        float a = HRT_Q4_ROUTE_A_DEFAULT;
+        if (const char* e = getenv("HRT_Q4_ROUTE_A")) { const float v = (float)atof(e); if (v > 0.0f) a = v; }
+        sc->ds.q4_route_a2 = a * a;
+        sc->ds.ref_fold_all = getenv("HRT_REF_FOLD_ALL") ? 1 : 0;   // tests: the megakernel / test kernels fold instead of walking
+    }
     sc->ds.texels_u8 = d_u8; sc->ds.texels_f32 = d_f32;
     sc->ds.n_prims = (int32_t)f->n_prims;
     sc->ds.background_tex = f->background_tex;

@@ -2,7 +2,9 @@
 // 16-byte aligned records the kernels fetch with dwordx4 loads (DScene in
 // hrt_device.h), and of its BVH nodes into the compact culling records.  Used by hrt_scene_create (hrt_hip.hip).
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <string>
 #include <vector>
 
 #include "../../include/hrt.h"
@@ -10,10 +12,127 @@
 
 namespace hrt {
 
+// ITriangle::boundingBox (triangle.cpp:133-151): min / max of the vertices, padded by 0.0001.
+inline void padded_tri_box(const float* p /* 9 floats */, float* mn, float* mx) {
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = gmin(gmin(p[c], p[3 + c]), p[6 + c]) - 0.0001f;
+        mx[c] = gmax(gmax(p[c], p[3 + c]), p[6 + c]) + 0.0001f;
+    }
+}
+
+// The REFERENCE's own tree of every mesh (bvh.cpp:6-61), for the rays that must be walked through it node by node
+// (hrt_device.h ref_walk: quirk Q-4 with a vanishing direction component on the shear axis, where ITriangle::hit's t no
+// longer agrees with the boxes and the winner depends on that tree's visiting order).
+// The tree is not shipped over the ABI, it is implied by what is: the reference sorts and splits at start + n / 2
+// (bvh.cpp:39-43) until one or two objects are left (bvh.cpp:20-36), so a node is a contiguous range of the depth-first
+// triangle order -- hrt_flat_scene::tri_ref_order holds each triangle's (range start << 1) | side -- and its box is the
+// union of the padded triangle boxes of its range (bvh.cpp:52-60: surroundingBox is min / max, exact and associative).
+//   nodes: 8 words per BVHNode, in PREORDER (= the order BVHNode::hit visits them, bvh.cpp:69-78: box, left, right), threaded:
+//          | min.xyz  skip | max.xyz  leaf |   skip = the node that follows this node's subtree (mesh-local; == node count
+//          at the end); the node after an inner node whose box passed is simply the next one.
+//          leaf = 0x80000000 | index of the `right` child for an inner node (`left` is the next node), else
+//          (first << 1) | (count - 1): `count` (1 or 2) triangles at positions first, first + 1 of `tris` (mesh-local;
+//          fewer than 2^28 triangles per mesh), `left` first (bvh.cpp:74-75).  (A one-object node has left == right,
+//          bvh.cpp:20-23, and tests its triangle twice; the second test cannot change the record and is left out.)
+//   tris : 3 x float4 per triangle in the reference's TEST order: v0.xyz | mesh-local triangle index (bits), v1.xyz_, v2.xyz_
+//   mesh_nodes: 4 words per mesh: first node, node count, first triangle of the mesh in `tris`, 0
+// tri_ref_order == NULL: the triangles are taken in the given order (a reference tree whose sorts changed nothing);
+// `codes` / `leaf_box` then hold what tri_ref_order / tri_box would have said (pack_triangles uses them).
+struct RefTree {
+    std::vector<uint32_t> nodes;
+    std::vector<float> tris;
+    std::vector<uint32_t> mesh_nodes;
+    std::vector<uint32_t> codes;      // per triangle (global index)
+    std::vector<float> leaf_box;      // 6 floats per triangle: the box of its lowest BVHNode
+};
+namespace detail {
+struct RefBuilder {
+    const float* pos;                 // mesh's tri_pos (9 floats per triangle)
+    const std::vector<uint32_t>* ord; // depth-first order: mesh-local triangle indices
+    std::vector<uint32_t>* nodes;
+    uint32_t first_node;              // of this mesh, in *nodes (8 words each)
+    // builds the subtree over ord[start, start + n); returns its box in bmn / bmx
+    void build(uint32_t start, uint32_t n, float* bmn, float* bmx) {
+        const size_t me = nodes->size() / 8;
+        nodes->resize(nodes->size() + 8, 0u);
+        uint32_t leaf;
+        if (n <= 2) {
+            padded_tri_box(pos + 9 * (size_t)(*ord)[start], bmn, bmx);
+            if (n == 2) {   // AABB::surroundingBox (aabb.h:41-56)
+                float mn2[3], mx2[3];
+                padded_tri_box(pos + 9 * (size_t)(*ord)[start + 1], mn2, mx2);
+                for (int c = 0; c < 3; ++c) { bmn[c] = gmin(bmn[c], mn2[c]); bmx[c] = gmax(bmx[c], mx2[c]); }
+            }
+            leaf = (start << 1) | (n - 1);
+        } else {
+            float lmn[3], lmx[3], rmn[3], rmx[3];
+            build(start, n / 2, lmn, lmx);
+            leaf = 0x80000000u | (uint32_t)(nodes->size() / 8 - first_node);   // where `right` is about to be put
+            build(start + n / 2, n - n / 2, rmn, rmx);
+            for (int c = 0; c < 3; ++c) { bmn[c] = gmin(lmn[c], rmn[c]); bmx[c] = gmax(lmx[c], rmx[c]); }
+        }
+        uint32_t* w = nodes->data() + 8 * me;
+        for (int c = 0; c < 3; ++c) { w[c] = f2u(bmn[c]); w[4 + c] = f2u(bmx[c]); }
+        w[3] = (uint32_t)(nodes->size() / 8 - first_node);
+        w[7] = leaf;
+    }
+};
+}  // namespace detail
+// false (+ *err): tri_ref_order is not the depth-first code of such a tree.
+inline bool pack_ref_tree(const hrt_flat_scene* f, RefTree& out, std::string* err = nullptr) {
+    const size_t nt = (size_t)f->n_tris;
+    out.nodes.clear(); out.tris.clear(); out.mesh_nodes.assign((size_t)f->n_meshes * 4, 0u);
+    out.codes.assign(nt, 0u); out.leaf_box.assign(nt * 6, 0.0f);
+    for (uint32_t m = 0; m < f->n_meshes; ++m) {
+        const hrt_mesh& me = f->meshes[m];
+        const uint32_t n = me.tri_count;
+        out.mesh_nodes[4 * m] = (uint32_t)(out.nodes.size() / 8);
+        const size_t tri_base = out.tris.size() / 12;   // (meshes may share triangle ranges: every mesh gets its own copy)
+        out.mesh_nodes[4 * m + 2] = (uint32_t)tri_base;
+        if (n == 0) continue;
+        out.tris.resize(out.tris.size() + 12 * (size_t)n, 0.0f);
+        std::vector<uint32_t> ord(n);
+        for (uint32_t i = 0; i < n; ++i) ord[i] = i;
+        if (f->tri_ref_order) {
+            const uint32_t* code = f->tri_ref_order + me.tri_first;
+            std::sort(ord.begin(), ord.end(), [code](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+        }
+        detail::RefBuilder rb;
+        rb.pos = f->tri_pos + 9 * (size_t)me.tri_first; rb.ord = &ord; rb.nodes = &out.nodes; rb.first_node = out.mesh_nodes[4 * m];
+        float mn[3], mx[3];
+        rb.build(0, n, mn, mx);
+        const uint32_t count = (uint32_t)(out.nodes.size() / 8) - rb.first_node;
+        out.mesh_nodes[4 * m + 1] = count;
+        // the leaves: codes, leaf-level boxes, triangles in test order
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t* w = out.nodes.data() + 8 * ((size_t)rb.first_node + i);
+            if (w[7] & 0x80000000u) continue;
+            const uint32_t first = w[7] >> 1, cnt = (w[7] & 1u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t tri = ord[first + k];
+                const uint32_t code = (first << 1) | k;
+                if (f->tri_ref_order && f->tri_ref_order[me.tri_first + tri] != code) {
+                    if (err) *err = "tri_ref_order is not the depth-first code of a median-split tree (mesh " + std::to_string(m) + ", triangle " + std::to_string(tri) + ")";
+                    return false;
+                }
+                const size_t g = (size_t)me.tri_first + tri;
+                out.codes[g] = code;
+                for (int c = 0; c < 3; ++c) { out.leaf_box[6 * g + c] = u2f(w[c]); out.leaf_box[6 * g + 3 + c] = u2f(w[4 + c]); }
+                float* t = &out.tris[12 * (tri_base + first + k)];
+                const float* p = rb.pos + 9 * (size_t)tri;
+                for (int v = 0; v < 3; ++v) { t[4 * v] = p[3 * v]; t[4 * v + 1] = p[3 * v + 1]; t[4 * v + 2] = p[3 * v + 2]; }
+                t[3] = u2f(tri);
+            }
+        }
+    }
+    return true;
+}
+
 //   pos : 3 x float4 per triangle  v0.xyz_ v1.xyz_ v2.xyz_
 //   attr: 4 x float4 per triangle  n0.xyz uv0.x | n1.xyz uv0.y | n2.xyz uv1.x | uv1.y uv2.x uv2.y _
 //   box : 2 x float4 per triangle  accept-box min.xyz + tri_ref_order code (raw bits) | max.xyz _
-inline void pack_triangles(const hrt_flat_scene* f, std::vector<float>& pos, std::vector<float>& attr, std::vector<float>& box) {
+// `ref` (pack_ref_tree's result) supplies the codes / leaf-level boxes the scene did not bring (tri_ref_order / tri_box == NULL).
+inline void pack_triangles(const hrt_flat_scene* f, const RefTree& ref, std::vector<float>& pos, std::vector<float>& attr, std::vector<float>& box) {
     const size_t nt = (size_t)f->n_tris;
     pos.assign(nt * 12, 0.0f); attr.assign(nt * 16, 0.0f); box.assign(nt * 8, 0.0f);
     for (size_t i = 0; i < nt; ++i) {
@@ -25,18 +144,9 @@ inline void pack_triangles(const hrt_flat_scene* f, std::vector<float>& pos, std
         a[8] = n[6]; a[9] = n[7]; a[10] = n[8]; a[11] = uv[2];
         a[12] = uv[3]; a[13] = uv[4]; a[14] = uv[5];
         float* b = &box[8 * i];
-        if (f->tri_box) {
-            const float* s = f->tri_box + 6 * i;
-            b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[4] = s[3]; b[5] = s[4]; b[6] = s[5];
-        } else {  // triangle.cpp:133-151
-            for (int c = 0; c < 3; ++c) {
-                float mn = gmin(gmin(p[c], p[3 + c]), p[6 + c]);
-                float mx = gmax(gmax(p[c], p[3 + c]), p[6 + c]);
-                b[c] = mn - 0.0001f; b[4 + c] = mx + 0.0001f;
-            }
-        }
-        const uint32_t ord = f->tri_ref_order ? f->tri_ref_order[i] : ((uint32_t)i << 1);
-        b[3] = u2f(ord);
+        const float* s = f->tri_box ? f->tri_box + 6 * i : &ref.leaf_box[6 * i];
+        b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[4] = s[3]; b[5] = s[4]; b[6] = s[5];
+        b[3] = u2f(ref.codes[i]);
     }
 }
 

@@ -235,8 +235,10 @@ def test_wavefront_sample_chunking_and_paths_agree(teapot, monkeypatch):
             assert np.array_equal(one.view(np.uint32), img.view(np.uint32)) and st.rays == s1.rays, f"task size {ts}, tail round {tr}"
     monkeypatch.delenv("HRT_WF_TASK_SIZE"); monkeypatch.delenv("HRT_WF_TAIL_ROUND")
     # hrt_stats.traversal_*: what the k_wf_ext LAUNCHES tested (the rest: root-filter tests of gen/pre/shade and the tail's rounds)
-    assert tails[0].traversal_box_tests == 0 and tails[0].traversal_tri_tests == 0
-    assert 0 < tails[1].traversal_box_tests < tails[2].traversal_box_tests < tails[3].traversal_box_tests < s1.box_tests
+    # (tail round 1 still launches round 0's k_wf_ext: under Q-1 the root filter turns every camera ray away, except the few
+    #  that walk the reference's tree -- Q-4 with a vanishing direction component on the shear axis, hrt_device.h ref_walk)
+    assert tails[0].traversal_box_tests < 2000 and tails[0].traversal_tri_tests < 200
+    assert tails[0].traversal_box_tests < tails[1].traversal_box_tests < tails[2].traversal_box_tests < tails[3].traversal_box_tests < s1.box_tests
     assert s1.traversal_box_tests == 0          # this tile is a tiny batch: by default its tasks run all rounds inside k_wf_tail
     assert tails[3].traversal_tri_tests == s1.tri_tests
     for a in (s2, s3, s4, s5, *tails):
@@ -264,9 +266,9 @@ def test_headline_frame_at_full_size_against_the_oracle(built, tmp_path):
     """BASELINE.json's headline workload in full -- teapot_scene.yaml, 640 x 640, 100 spp, 2.8e8 / 3.4e8 path segments -- rendered
     by the pipeline and by the oracle (about 20 + 30 s on the box's 16 host threads).
       quirks=fixed:     every one of the 409 600 linear fp32 pixels and the segment count identical.
-      quirks=reference: identical but for the documented Q-4 residual (a path whose direction component
-                        on the origin-chosen shear axis vanishes): measured 53 pixels and 6 of 1 228 800 u8 values, segment
-                        counts 37 apart; bounded here at 200 pixels / 40 u8 values / 400 segments."""
+      quirks=reference: the same (round 1 left 53 pixels and 37 segments apart: paths with a vanishing direction component on
+                        the origin-chosen shear axis of Q-4, whose t is noise and whose winner is decided by the visiting
+                        order of the reference's own tree -- they walk that tree now, hrt_device.h ref_walk)."""
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
     api.write_teapot_obj(str(tmp_path / "teapot.obj"), 1.0)
@@ -284,8 +286,8 @@ def test_headline_frame_at_full_size_against_the_oracle(built, tmp_path):
     p = api.default_params(W, H, 100, quirks=api.QUIRKS_REFERENCE, stats=True)
     ref, sr = world.render_tile(cam, p)
     img, st = dev.render_tile(cam, p)
-    differing = ((img.view(np.uint32) != ref.view(np.uint32)) & ~(np.isnan(img) & np.isnan(ref))).any(2)
-    assert abs(int(st.rays) - int(sr.rays)) <= 400 and sr.rays > 3e8
-    assert differing.sum() <= 200, differing.sum()
-    assert (dev.resolve_u8(img) != orc.resolve_u8(ref)).sum() <= 40
+    assert st.rays == sr.rays and sr.rays > 3e8
+    same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))     # (NaN payloads differ; film.cpp:35-37 scrubs them)
+    assert same.all(), int((~same).any(2).sum())
+    assert np.array_equal(dev.resolve_u8(img), orc.resolve_u8(ref))
     dev.close()

@@ -7,6 +7,7 @@
 // localise a rare GPU/oracle mismatch.  It is NOT part of the product: nothing under hobbyraytracer_amd/
 // or include/ references it, it is never installed into lib/, and the product has no CPU render path.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,11 +25,20 @@ namespace {
 struct CpuScene {
     std::vector<float> pos, attr, box, grids;
     std::vector<uint32_t> qnodes;
+    RefTree ref;
     DScene ds;
 };
 CpuScene* make(const hrt_flat_scene* f) {
     CpuScene* s = new CpuScene;
-    pack_triangles(f, s->pos, s->attr, s->box);
+    if (!pack_ref_tree(f, s->ref)) { delete s; return nullptr; }
+    pack_triangles(f, s->ref, s->pos, s->attr, s->box);
+    s->ds.rnodes = (const uint4*)s->ref.nodes.data(); s->ds.rtris = (const float4*)s->ref.tris.data(); s->ds.rmesh = (const uint4*)s->ref.mesh_nodes.data();
+    {
+        float a = HRT_Q4_ROUTE_A_DEFAULT;
+        if (const char* e = getenv("HRT_Q4_ROUTE_A")) a = (float)atof(e);
+        s->ds.q4_route_a2 = a * a;
+        s->ds.ref_fold_all = getenv("HRT_REF_FOLD_ALL") ? 1 : 0;
+    }
     s->ds.prims = f->prims; s->ds.mats = f->materials; s->ds.texs = f->textures; s->ds.meshes = f->meshes;
     pack_nodes(f, s->qnodes, s->grids);
     s->ds.qnodes = (const uint4*)s->qnodes.data(); s->ds.grids = (const float4*)s->grids.data();
