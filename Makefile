@@ -20,7 +20,7 @@ all: $(PKG)/lib/libhrt_hip.so $(PKG)/lib/libhrt_host.so $(PKG)/bin/hobbyraytrace
 
 $(PKG)/lib/libhrt_hip.so: $(PKG)/csrc/hrt_hip.hip $(HOST_HDR)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $< -ldl
 
 $(PKG)/lib/libhrt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(PKG)/lib

@@ -123,7 +123,8 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 HIP_SYMBOLS = ["hrt_device_count", "hrt_scene_create", "hrt_scene_destroy", "hrt_render_tile", "hrt_render_stripes_device",
                "hrt_render_stripes", "hrt_render_stripes_accumulate_device", "hrt_render_stripes_accumulate", "hrt_stripe_rows", "hrt_stripe_row_index", "hrt_scene_stats", "hrt_resolve_u8",
-               "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version"]
+               "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version",
+               "hrt_multi_create", "hrt_multi_destroy", "hrt_multi_devices", "hrt_multi_uses_rccl", "hrt_multi_render"]
 HOST_SYMBOLS = ["hrt_host_load_yaml", "hrt_host_free", "hrt_host_flat", "hrt_host_film", "hrt_host_camera", "hrt_host_bvh_depth",
                 "hrt_default_params", "hrt_asset_write_teapot_obj", "hrt_asset_write_bust_obj", "hrt_asset_write_hall_hdr",
                 "hrt_host_write_image", "hrt_host_read_hdr", "hrt_host_read_png", "hrt_host_read_jpeg", "hrt_host_write_hdr", "hrt_host_write_pfm", "hrt_host_read_pfm", "hrt_host_last_error"]
@@ -165,6 +166,14 @@ _hip.hrt_scene_stats.argtypes = [_vp, C.POINTER(Stats)]
 _hip.hrt_resolve_u8.argtypes = [_vp, _fp, C.c_int64, _u8p]
 _hip.hrt_resolve_u8_device.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
 _hip.hrt_closest_hit.argtypes = [_vp, C.POINTER(Params), C.c_int64, _fp, _fp, C.c_float, C.c_float, C.c_uint32, C.POINTER(Hit)]
+_hip.hrt_multi_create.argtypes = [C.POINTER(FlatScene), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_vp)]
+_hip.hrt_multi_destroy.argtypes = [_vp]
+_hip.hrt_multi_destroy.restype = None
+_hip.hrt_multi_devices.argtypes = [_vp]
+_hip.hrt_multi_devices.restype = C.c_int32
+_hip.hrt_multi_uses_rccl.argtypes = [_vp]
+_hip.hrt_multi_uses_rccl.restype = C.c_int32
+_hip.hrt_multi_render.argtypes = [_vp, C.POINTER(Camera), C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _u8p, C.POINTER(Stats)]
 _hip.hrt_math_probe.argtypes = [C.c_int, C.c_int32, C.c_int64, _fp, _fp, _fp]
 
 _host.hrt_host_last_error.restype = C.c_char_p
@@ -438,6 +447,43 @@ class DeviceScene:
         _check(_hip.hrt_closest_hit(self._h, C.byref(params), n, _ptr(o), _ptr(d), t_min, t_max, pixel0,
                                     out.ctypes.data_as(C.POINTER(Hit))))
         return out
+
+
+class MultiScene:
+    """hrt_multi_*: the flat scene on several devices of this process + the RCCL gather of their film stripes."""
+
+    def __init__(self, flat, devices=(0,), force_rccl=False):
+        flat_ptr = flat if not isinstance(flat, FlatScene) else C.pointer(flat)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = _vp()
+        _check(_hip.hrt_multi_create(flat_ptr, len(devices), devs, 1 if force_rccl else 0, C.byref(h)))
+        self._h = h
+        self._keep = flat
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _hip.hrt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self):
+        return bool(_hip.hrt_multi_uses_rccl(self._h))
+
+    def render(self, cam, params, rows_per_block=8, sample_first=0, sample_count=-1, resume_sums=None, want_u8=True):
+        """-> (sums or means [H, W, 3] float32, u8 film [H, W, 3] or None, Stats)"""
+        sums = np.empty((params.height, params.width, 3), dtype=np.float32)
+        u8 = np.empty((params.height, params.width, 3), dtype=np.uint8) if want_u8 else None
+        rs = None if resume_sums is None else _f32(resume_sums)
+        st = Stats()
+        _check(_hip.hrt_multi_render(self._h, C.byref(cam), C.byref(params), rows_per_block, sample_first, sample_count,
+                                     _ptr(rs) if rs is not None else None, _ptr(sums), _ptr(u8, _u8p) if want_u8 else None, C.byref(st)))
+        return sums, u8, st
 
 
 def math_probe(op, a, b=None, device=0):

@@ -492,10 +492,29 @@ struct MeshRay {          // a ray in mesh space plus its per-ray constants
     TriRay tr;            // exact-arithmetic constants of the triangle test
     float idx, idy, idz;  // culling-only constants (free to differ from the reference: see header): 1/d,
     float gx, gy, gz;     // and the slab test in the mesh's node-grid coordinates: t = q * g - o_ (q = 16-bit grid index)
+    float reach;          // mesh_ray_reach (only until mesh_ray_grid has run)
     float oxl, oxh, oyl, oyh, ozl, ozh;   // (o - origin) / d per axis, shifted for the LOW / HIGH face of a box (see mesh_ray_grid)
 };
+// Q-4: the shear axis comes from the ray ORIGIN (triangle.cpp:70), so the t of ITriangle::hit is only good to about
+// kappa * eps * M / |d[kZ]| (M = the size of the coordinates that cancel in v - o; kappa in the hundreds for a thin triangle
+// met near an edge).  A triangle of the surface the ray has just LEFT -- truly behind the origin by less than that --
+// then reports a small positive t, and the reference takes it if the box of its lowest node (the union with its
+// neighbour in the tree) reaches the ray: at |d| / |d[kZ]| = 45 a triangle 3.9e-4 behind the origin came out at
+// t = +2.0e-5 (tests/tools/gpu_fuzz_meshes.py; one path in 2e8).  The culling boxes here are this tree's own, and the ray
+// starts outside them: so every slab is widened by that reach (in t, both ways: the same shift as above), which lets the
+// walk look that far behind the origin and beyond a box's far side.  1e-4 * M / |d[kZ]|: 20x what was seen; a few 1e-4
+// units for an ordinary ray, 1e-2 at the |d| / |d[kZ]| = 128 beyond which rays walk the reference's tree anyway.
+__device__ inline float mesh_ray_reach(vec3 o, float sZ, float4 origin, float4 step, uint32_t quirks) {
+    if (!(quirks & HRT_Q4_SHEAR_FROM_ORIGIN)) return 0.0f;
+    const float M = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(origin.x) + 65535.0f * step.x), fmaxf(fabsf(o.y), fabsf(origin.y) + 65535.0f * step.y)),
+                          fmaxf(fabsf(o.z), fabsf(origin.z) + 65535.0f * step.z));
+    const float reach = 1e-4f * fabsf(sZ) * M;
+    return reach < 1e30f ? reach : 0.0f;           // (NaN rays keep their own rules; d[kZ] == 0 walks the reference's tree)
+}
 // box = origin + q * step  =>  t = (box - o) / d = q * (step / d) - (o - origin) / d
-__device__ inline void mesh_ray_grid(MeshRay& r, float4 origin, float4 step) {
+// `reach`: every slab is also widened by the reach of a meaningless t under quirk Q-4 (mesh_ray_reach below; computed where the
+// ray is prepared and carried in its record: the traversal kernel's registers are counted).
+__device__ inline void mesh_ray_grid(MeshRay& r, float4 origin, float4 step, float reach) {
     r.gx = r.idx * step.x; r.gy = r.idy * step.y; r.gz = r.idz * step.z;
     const float ox = (r.o.x - origin.x) * r.idx, oy = (r.o.y - origin.y) * r.idy, oz = (r.o.z - origin.z) * r.idz;
     // t = q * g - o_ carries the rounding of both terms: up to ~1.2e-7 of their magnitudes, which is no longer small
@@ -503,8 +522,9 @@ __device__ inline void mesh_ray_grid(MeshRay& r, float4 origin, float4 step) {
     // were culled, at 1e6 units 1863).  The reference's own slab test rounds just as badly but is not what culls here,
     // so every slab is widened by s = 4e-7 x (largest |q * g| + |o_|) at no cost in the loop: the face the ray ENTERS
     // through gets o_ + s, the one it leaves through o_ - s, and which is which is the sign of g, known per ray.
-    const float sx = 4e-7f * (fabsf(r.gx) * 65535.0f + fabsf(ox)), sy = 4e-7f * (fabsf(r.gy) * 65535.0f + fabsf(oy)),
-                sz = 4e-7f * (fabsf(r.gz) * 65535.0f + fabsf(oz));
+    float sx = 4e-7f * (fabsf(r.gx) * 65535.0f + fabsf(ox)), sy = 4e-7f * (fabsf(r.gy) * 65535.0f + fabsf(oy)),
+          sz = 4e-7f * (fabsf(r.gz) * 65535.0f + fabsf(oz));
+    sx += reach; sy += reach; sz += reach;
     r.oxl = r.gx < 0 ? ox - sx : ox + sx; r.oxh = r.gx < 0 ? ox + sx : ox - sx;
     r.oyl = r.gy < 0 ? oy - sy : oy + sy; r.oyh = r.gy < 0 ? oy + sy : oy - sy;
     r.ozl = r.gz < 0 ? oz - sz : oz + sz; r.ozh = r.gz < 0 ? oz + sz : oz - sz;
@@ -533,11 +553,17 @@ __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4
         if (fabsf(r.idy) * my > 1e37f) r.idy = copysignf(1e37f / my, r.idy);
         if (fabsf(r.idz) * mz > 1e37f) r.idz = copysignf(1e37f / mz, r.idz);
     }
-    mesh_ray_grid(r, origin, step);
+    r.reach = mesh_ray_reach(o, r.tr.sZ, origin, step, quirks);
+    mesh_ray_grid(r, origin, step, r.reach);
     return r;
 }
 #define HRT_TRAV_DONE 0x7fffffff
 #define HRT_TIE_SELF 0x40000000   // TravState::best flag: the hit so far passes triangle.cpp:106-109 against its own t
+#define HRT_TIE_OVERFLOW 0xfffffffeu   // TravState::self_order while there is no self-hit: more near-tie contenders than the one note holds
+// WorldHit::sub flag of the wavefront pipeline: the traversal met such a tie; the triangle recorded is its own best guess (its t
+// is within an ulp or two of the reference's), and world_rec settles it with ref_walk before the hitRecord is built.  (Not in
+// the traversal kernel itself: its register budget is counted, tests/test_kernel_resources.py.)
+#define HRT_SUB_TIE_UNSETTLED 0x40000000
 struct TravState {
     float closest;        // t_max, shrinking
     int best;             // closest accepted triangle so far (mesh-local index) or -1
@@ -684,9 +710,19 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
                 const float lim_l = ts.self_t * ev.det;
                 take = ev.det < 0 ? !(ev.tScaled < lim_l) : !(ev.tScaled > lim_l);
             } else {
-                // this is `left`, the kept one is `right`, which the reference tests after this one: `right` survives
-                // if it is closer, or -- same t -- if it passes the comparison against its own rounded t
-                take = ts.self_t > t || (ts.self_t == t && !(ts.self_tri & HRT_TIE_SELF));
+                // this is `left`, the kept one is `right`, which the reference tests AFTER this one with t_max = this t
+                // (bvh.cpp:75): `right` stays unless triangle.cpp:106-109 find it strictly beyond that -- a comparison of ITS
+                // tScaled with fl(t * det), which it can pass with a t one ulp LARGER than this one (a ray leaving the shared edge
+                // of a front- and a back-facing triangle: both report t ~ 1e-6, tests/tools/gpu_fuzz_meshes.py).  The kept
+                // triangle's tScaled and det are not kept: evaluate it again (a cold path: two self-hits in one node).
+                const int rt = ts.self_tri & ~HRT_TIE_SELF;
+                const float4 r0 = tpos[3 * rt + 0], r1 = tpos[3 * rt + 1], r2 = tpos[3 * rt + 2];
+                TriEval er;
+                take = true;
+                if (tri_eval(r.tr, vec3(r0.x, r0.y, r0.z), vec3(r1.x, r1.y, r1.z), vec3(r2.x, r2.y, r2.z), er)) {
+                    const float lim_r = t * er.det;
+                    take = er.det < 0 ? (er.tScaled < lim_r) : (er.tScaled > lim_r);
+                }
             }
             if (take) {
                 const float own = t * ev.det;
@@ -702,9 +738,18 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
             // can be turned down although its t is an ulp smaller, or taken although it is equal -- so the winner depends on
             // who is met first.  Here the walk keeps the closer one as usual and remembers the other (in `self_tri`, unused until a self-hit); trav_result
             // replays the pair in the reference's order.
-            if (farther) ts.self_tri = (int)ti;
-            else {
-                if (near) ts.self_tri = ts.best;
+            // A THIRD contender (three hits within an ulp or two: a vertex shared by faces seen edge-on) cannot be settled from
+            // one note: the reference's fold over them is not transitive.  Such a ray walks the reference's tree (trav_tie_overflow).
+            if (farther) {
+                if (ts.self_tri >= 0 && ts.self_tri != (int)ti && t == t) ts.self_order = HRT_TIE_OVERFLOW;
+                ts.self_tri = (int)ti;
+            } else {
+                if (near) {
+                    // (not for NaN: a NaN ray passes every box and "hits" every triangle with t = NaN -- all of them "near" each
+                    //  other; the record is NaN whichever stays, and a walk of the whole reference tree per such ray is 8 ms)
+                    if (ts.self_tri >= 0 && ts.self_tri != ts.best && t == t) ts.self_order = HRT_TIE_OVERFLOW;
+                    ts.self_tri = ts.best;
+                }
                 ts.closest = t;
                 ts.best = (int)ti;
             }
@@ -713,6 +758,9 @@ __device__ inline void trav_leaf(const float4* __restrict__ tpos, const float4* 
     if (ts.sp > 0) { --ts.sp; ts.cur = stack[ts.sp * HRT_BLOCK]; }
     else ts.cur = HRT_TRAV_DONE;
 }
+// More than two hits within an ulp or two of each other were met (and no self-hit, which would decide anyway): the result must
+// come from ref_walk, the reference's own walk.
+__device__ inline bool trav_tie_overflow(const TravState& ts) { return !ts.selfhit && ts.self_order == HRT_TIE_OVERFLOW; }
 // Result of a finished traversal: winning triangle (or -1) and its t.  A remembered near-tie (ts.self_tri without a self-hit) is settled the way the
 // reference's walk would have: F = the one of the pair its tree meets first, S = the other; F stands unless S, tested with
 // t_max = t_F (bvh.cpp:75 / the running closest), passes triangle.cpp:106-109 and its leaf-level box (aabb.h:26-39).
@@ -771,6 +819,10 @@ __device__ inline int bvh_traverse(const DScene& sc, int mi /* mesh index */, ve
     while (ts.cur != HRT_TRAV_DONE) {
         while (trav_at_inner(ts)) trav_inner<STATS>(nodes, r, ts, t_lo, stack, cnt);
         if (trav_at_leaf(ts)) trav_leaf<STATS>(tpos, tbox, r, ts, t_min, quirks, stack, cnt);
+    }
+    if (trav_tie_overflow(ts)) {
+        const HRT_CONST_AS uint32_t* rm = uniform_table((const uint32_t*)sc.rmesh) + 4 * mi;
+        return ref_walk<STATS>(sc.rnodes + 2ull * rm[0], sc.rtris + 3ull * rm[2], rm[1], o, d, r.tr, t_min, mesh_t_max(t_max), quirks, t_out, cnt);
     }
     return trav_result(ts, tpos, tbox, r, t_min, t_out);
 }
@@ -855,7 +907,7 @@ __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o,
 }
 
 // Rebuilds the winner's hitRecord exactly as the reference's call chain does.
-__device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, DRec& rec) {
+__device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, float t_min_for_ties, DRec& rec) {
     const hrt_prim& pr = sc.lprims[wh.prim];
     vec3 lo = o, ld = d;
     const int n = pr.n_xforms;
@@ -881,7 +933,20 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     rec.mat = pr.material;
     rec.frontFace = true;
     const int kind = pr.kind;
-    if (kind == HRT_PRIM_MESH) tri_rec(sc, sc.lmeshes[pr.mesh], wh.sub, lo, ld, quirks, rec);
+    if (kind == HRT_PRIM_MESH) {
+        int tri = wh.sub;
+        if (tri & HRT_SUB_TIE_UNSETTLED) {
+            // three or more hits within an ulp or two of each other: the reference's own walk decides (from a t_max just beyond
+            // them: whatever lay clearly nearer would have won already)
+            const uint32_t* rm = (const uint32_t*)sc.rmesh + 4 * pr.mesh;      // (a per-lane index: plain loads)
+            DCounters none; none.box_tests = 0; none.tri_tests = 0;
+            float t_settled;
+            const int exact = ref_walk<false>(sc.rnodes + 2ull * rm[0], sc.rtris + 3ull * rm[2], rm[1], lo, ld, tri_ray_setup(lo, ld, quirks), t_min_for_ties,
+                                              wh.t + fabsf(wh.t) * 4e-6f, quirks, t_settled, none);
+            tri = exact >= 0 ? exact : (tri & ~HRT_SUB_TIE_UNSETTLED);
+        }
+        tri_rec(sc, sc.lmeshes[pr.mesh], tri, lo, ld, quirks, rec);
+    }
     else if (kind == HRT_PRIM_SPHERE) sphere_rec(pr.p, lo, ld, wh.t, rec);
     else if (kind == HRT_PRIM_BOX) box_rec(pr.p, lo, ld, wh.t, wh.sub, rec);
     else if (kind == HRT_PRIM_MEDIUM) {  // constantMedium.cpp:30-36
@@ -1051,7 +1116,7 @@ __device__ inline bool path_shade(const DScene& sc, const hrt_params& pr, const 
     }
     if (STATS && sc.lprims[wh.prim].kind == HRT_PRIM_MESH) pc.mesh_hits++;
     DRec rec;
-    world_rec(sc, wh, ps.o, ps.d, pr.quirks, rec);
+    world_rec(sc, wh, ps.o, ps.d, pr.quirks, pr.t_min, rec);
     vec3 emitted, attenuation, so, sd;
     const bool b = material_scatter(sc, rec, ps.d, ctx, emitted, attenuation, so, sd);
     ps.result += ps.atten * emitted;

@@ -13,6 +13,8 @@
 //   k_closest_hit       world->hit() for test rays (parity tests).
 //   k_math_probe        the shared math kernels, for CPU==GPU bit tests.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is loaded on demand (rccl_api below)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -21,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hrt_device.h"
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_closest_hit(DScene sc, hrt_params
     h.prim = wh.prim; h.tri = -1;
     if (wh.prim >= 0) {
         DRec rec;
-        world_rec(sc, wh, o, d, pr.quirks, rec);
+        world_rec(sc, wh, o, d, pr.quirks, t_min, rec);
         h.t = rec.t;
         h.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? wh.sub : -1;
         h.front_face = rec.frontFace ? 1 : 0;
@@ -390,7 +393,7 @@ __device__ inline void wf_store_record(const WfBuf& w, unsigned q, const MeshRay
     w.E0[q] = make_float4(mr.o.x, mr.o.y, mr.o.z, mesh_t_max(closest));   // what the traversal starts from: NaN -> +inf
     w.E1[q] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pos));
     w.E2[q] = make_float4(mr.tr.sX, mr.tr.sY, mr.tr.sZ, __int_as_float(mr.tr.kZ));
-    w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, 0.0f);
+    w.E3[q] = make_float4(mr.idx, mr.idy, mr.idz, mr.reach);
 }
 // record of a ray for ref_walk: no culling constants
 __device__ inline void wf_store_ref_record(const WfBuf& w, unsigned q, const MeshRay& mr, float closest, unsigned pos) {
@@ -773,7 +776,7 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
                     r.o = vec3(e0.x, e0.y, e0.z); r.d = vec3(e1.x, e1.y, e1.z);
                     r.tr.o = r.o; r.tr.sX = e2.x; r.tr.sY = e2.y; r.tr.sZ = e2.z; r.tr.kZ = __float_as_int(e2.w);
                     r.idx = e3.x; r.idy = e3.y; r.idz = e3.z;
-                    mesh_ray_grid(r, em.grid_o, em.grid_s);
+                    mesh_ray_grid(r, em.grid_o, em.grid_s, e3.w);
                     pos = __float_as_uint(e1.w);
                     ts.closest = e0.w; ts.best = -1;        // (wf_store_record wrote mesh_t_max(closest))
                     ts.selfhit = false; ts.self_order = 0xffffffffu; ts.self_tri = -1; ts.self_t = 0.0f;
@@ -800,7 +803,8 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
             if (trav_at_leaf(ts)) trav_leaf<STATS>(em.tpos, em.tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
             if (ts.cur == HRT_TRAV_DONE) {
                 float t;
-                const int tri = trav_result(ts, em.tpos, em.tbox, r, pr.t_min, t);
+                int tri = trav_result(ts, em.tpos, em.tbox, r, pr.t_min, t);
+                if (tri >= 0 && trav_tie_overflow(ts)) tri |= HRT_SUB_TIE_UNSETTLED;      // three-way near-tie: world_rec settles it
                 if (tri >= 0) {
                     ((float*)&w.S0[par][pos])[3] = t;
                     ((float*)&w.S2[par][pos])[3] = __int_as_float(mesh_prim);
@@ -1082,6 +1086,28 @@ __global__ __launch_bounds__(256) void k_wf_reduce(const float4* __restrict__ ra
     }
 }
 
+// ---- multi-GPU film assembly (hrt_multi_render): the gathered stripes of all ranks -> film order, and back
+// gathered: G shares of `share` floats; rank g's share holds its rows_g x W x 3 floats (rows in increasing absolute order).
+__global__ __launch_bounds__(256) void k_unstripe(const float* __restrict__ gathered, float* __restrict__ film, int H, int W3, int R, int G, long long share) {
+    const long long n = (long long)H * W3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / W3), x = (int)(i - (long long)row * W3);
+        const int b = row / R, g = b % G, local = (b / G) * R + (row - b * R);     // block b belongs to rank b % G (hrt_stripe_row_index inverted)
+        film[i] = gathered[(long long)g * share + (long long)local * W3 + x];
+    }
+}
+__global__ __launch_bounds__(256) void k_restripe(const float* __restrict__ film, float* __restrict__ mine, int H, int W3, int R, int G, int rank, int rows) {
+    const long long n = (long long)rows * W3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int local = (int)(i / W3), x = (int)(i - (long long)local * W3);
+        const int b = local / R, row = (b * G + rank) * R + (local - b * R);
+        mine[i] = film[(long long)row * W3 + x];
+    }
+}
+__global__ __launch_bounds__(256) void k_preview_mean(const float* __restrict__ sums, float* __restrict__ mean, long long n, float samples_done) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) mean[i] = sums[i] / samples_done;
+}
+
 }  // namespace
 
 // ===================================================================== host side of the ABI
@@ -1172,6 +1198,23 @@ hrt_status validate(const hrt_flat_scene* f) {
             }
         }
     }
+    // tex_value (hrt_device.h) follows at most 4 CheckeredTextures before it reaches a leaf: deeper or cyclic nests are refused,
+    // not rendered cyan (the reference recurses without bound: a cycle there is a stack overflow)
+    for (uint32_t i = 0; i < f->n_textures; ++i) {
+        if (f->textures[i].kind != HRT_TEX_CHECKER) continue;
+        std::vector<std::pair<uint32_t, int>> st;
+        st.push_back({i, 1});
+        while (!st.empty()) {
+            auto [t, depth] = st.back(); st.pop_back();
+            if (f->textures[t].kind != HRT_TEX_CHECKER) continue;
+            if (depth > 4) return fail(HRT_ERR_UNSUPPORTED, "checkered textures nested more than 4 deep (or cyclic)");
+            st.push_back({(uint32_t)f->textures[t].even, depth + 1});
+            st.push_back({(uint32_t)f->textures[t].odd, depth + 1});
+        }
+    }
+    if (f->n_materials && !f->materials) return fail(HRT_ERR_INVALID, "materials is NULL");
+    if (f->n_meshes && !f->meshes) return fail(HRT_ERR_INVALID, "meshes is NULL");
+    if (f->n_nodes && !f->nodes) return fail(HRT_ERR_INVALID, "nodes is NULL");
     auto tex_ok = [&](int32_t t) { return t < 0 || (uint32_t)t < f->n_textures; };
     for (uint32_t i = 0; i < f->n_materials; ++i) {
         const hrt_material& m = f->materials[i];
@@ -1269,6 +1312,8 @@ hrt_status check_params(const hrt_params* p) {
     if (!p) return fail(HRT_ERR_INVALID, "params is NULL");
     if (p->width < 2 || p->height < 2) return fail(HRT_ERR_INVALID, "film must be at least 2x2 (main.cpp:120-121 divides by W-1, H-1)");
     if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HRT_ERR_UNSUPPORTED, "film larger than 2^30 pixels");
+    // the megakernel deals pixels in 8x8 tiles: the PADDED pixel count must fit 31 bits too (a 2 x 2^29 film pads to 2^32)
+    if (((int64_t)p->width + 7) / 8 * (((int64_t)p->height + 7) / 8) * 64 > (int64_t)0x7fffffff) return fail(HRT_ERR_UNSUPPORTED, "film too thin: its 8x8-tile padding exceeds 2^31 pixels");
     if (p->samples < 1) return fail(HRT_ERR_INVALID, "samples must be >= 1");
     if (p->max_depth < 1) return fail(HRT_ERR_INVALID, "max_depth must be >= 1");
     // the wavefront pipeline enqueues two launches and 3 KB of counters per round whether paths are left or not
@@ -1917,6 +1962,248 @@ hrt_status hrt_math_probe(int device, int32_t op, int64_t n, const float* in, co
     if (st == HRT_OK && (e = hipMemcpy(out, d_out, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) st = fail_hip(e, "hipMemcpy D2H");
     (void)hipFree(d_in); (void)hipFree(d_in2); (void)hipFree(d_out);
     return st;
+    HRT_API_CATCH
+}
+
+
+// ---------------------------------------------------------------- multi-GPU session: scene replicated on the
+// devices of this process, image rows dealt in interleaved blocks, one RCCL gather of the device-resident stripes over xGMI
+struct hrt_multi {
+    std::vector<int> devices;
+    std::vector<hrt_scene*> scenes;
+    std::vector<hipStream_t> streams;
+    std::vector<ncclComm_t> comms;       // empty until the first gather that needs them
+    std::vector<float*> d_accum;         // per rank: `share` floats (its stripes, padded to the largest share)
+    std::vector<float*> d_gather;        // per rank: G x share floats (ncclAllGather's receive buffer)
+    float* d_film = nullptr;             // first device: H x W x 3 sums in film order
+    float* d_mean = nullptr;             // first device: preview means
+    uint8_t* d_u8 = nullptr;
+    int W = 0, H = 0, R = 0;
+    long long share = 0;
+    bool use_rccl = false;
+};
+
+namespace {
+// RCCL is loaded when the first session asks for a communicator, not linked: a process that also hosts PyTorch (bench.py, the
+// tests) already has PyTorch's own copy of librccl, and two copies in one process end in a double free at exit.  dlopen by
+// soname hands back the copy that is already there, or /opt/rocm/lib's.
+struct RcclApi {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+}  // namespace
+}  // extern "C"
+namespace {
+const RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return a;
+        a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+        a.ok = a.CommInitAll && a.CommDestroy && a.AllGather && a.GroupStart && a.GroupEnd && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+extern "C" {
+namespace {
+hrt_status fail_nccl(ncclResult_t r, const char* what) { g_err = std::string(what) + ": " + (rccl_api().ok ? rccl_api().GetErrorString(r) : "RCCL not loaded"); return HRT_ERR_HIP; }
+#define NCCLCHK(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return fail_nccl(_r, #expr); } while (0)
+
+void multi_free_buffers(hrt_multi* m) {
+    for (size_t g = 0; g < m->devices.size(); ++g) {
+        (void)hipSetDevice(m->devices[g]);
+        if (g < m->d_accum.size() && m->d_accum[g]) (void)hipFree(m->d_accum[g]);
+        if (g < m->d_gather.size() && m->d_gather[g] && (m->use_rccl || g != 0)) (void)hipFree(m->d_gather[g]);
+    }
+    m->d_accum.clear(); m->d_gather.clear();
+    if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
+    if (m->d_film) (void)hipFree(m->d_film);
+    if (m->d_mean) (void)hipFree(m->d_mean);
+    if (m->d_u8) (void)hipFree(m->d_u8);
+    m->d_film = m->d_mean = nullptr; m->d_u8 = nullptr;
+    m->W = m->H = m->R = 0; m->share = 0;
+}
+hrt_status multi_reserve(hrt_multi* m, int W, int H, int R) {
+    if (m->W == W && m->H == H && m->R == R && !m->d_accum.empty()) return HRT_OK;
+    multi_free_buffers(m);
+    const int G = (int)m->devices.size();
+    m->share = (long long)hrt_stripe_rows(H, R, 0, G) * W * 3;        // rank 0 owns the most rows
+    if (m->share == 0) m->share = 4;
+    m->d_accum.assign(G, nullptr); m->d_gather.assign(G, nullptr);
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(hipSetDevice(m->devices[g]));
+        HIPCHK(hipMalloc((void**)&m->d_accum[g], (size_t)m->share * sizeof(float)));
+        HIPCHK(hipMemset(m->d_accum[g], 0, (size_t)m->share * sizeof(float)));
+        if (m->use_rccl) HIPCHK(hipMalloc((void**)&m->d_gather[g], (size_t)m->share * G * sizeof(float)));
+    }
+    if (!m->use_rccl) m->d_gather[0] = m->d_accum[0];                  // one device, no communicator: its stripes ARE the gathered buffer
+    HIPCHK(hipSetDevice(m->devices[0]));
+    HIPCHK(hipMalloc((void**)&m->d_film, (size_t)W * H * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&m->d_mean, (size_t)W * H * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&m->d_u8, (size_t)W * H * 3));
+    m->W = W; m->H = H; m->R = R;
+    return HRT_OK;
+}
+}  // namespace
+
+void hrt_multi_destroy(hrt_multi* m) {
+    if (!m) return;
+    multi_free_buffers(m);
+    for (size_t g = 0; g < m->comms.size(); ++g) if (m->comms[g]) (void)rccl_api().CommDestroy(m->comms[g]);
+    for (size_t g = 0; g < m->streams.size(); ++g) { (void)hipSetDevice(m->devices[g]); if (m->streams[g]) (void)hipStreamDestroy(m->streams[g]); }
+    for (hrt_scene* s : m->scenes) hrt_scene_destroy(s);
+    delete m;
+}
+
+hrt_status hrt_multi_create(const hrt_flat_scene* flat, int32_t n_devices, const int32_t* devices, int32_t force_rccl, hrt_multi** out) {
+    HRT_API_TRY
+    if (!out) return fail(HRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_devices < 1) return fail(HRT_ERR_INVALID, "n_devices must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(HRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    hrt_multi* m = new hrt_multi;
+    for (int g = 0; g < n_devices; ++g) {
+        const int d = devices ? devices[g] : g;
+        if (d < 0 || d >= ndev) { delete m; return fail(HRT_ERR_INVALID, "device index out of range"); }
+        for (int k : m->devices) if (k == d) { delete m; return fail(HRT_ERR_INVALID, "device listed twice"); }
+        m->devices.push_back(d);
+    }
+    m->use_rccl = n_devices > 1 || force_rccl != 0;
+    m->scenes.assign(n_devices, nullptr); m->streams.assign(n_devices, nullptr);
+    for (int g = 0; g < n_devices; ++g) {
+        hrt_status st = hrt_scene_create(flat, m->devices[g], &m->scenes[g]);
+        if (st != HRT_OK) { hrt_multi_destroy(m); return st; }
+        hipError_t e = hipStreamCreateWithFlags(&m->streams[g], hipStreamNonBlocking);
+        if (e != hipSuccess) { hrt_multi_destroy(m); return fail_hip(e, "hipStreamCreate"); }
+    }
+    if (m->use_rccl) {   // one communicator per device of this process (single process: ncclCommInitAll)
+        if (!rccl_api().ok) { hrt_multi_destroy(m); return fail(HRT_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded (needed for more than one device)"); }
+        m->comms.assign(n_devices, nullptr);
+        ncclResult_t r = rccl_api().CommInitAll(m->comms.data(), n_devices, m->devices.data());
+        if (r != ncclSuccess) { m->comms.clear(); hrt_multi_destroy(m); return fail_nccl(r, "ncclCommInitAll"); }
+    }
+    *out = m;
+    return HRT_OK;
+    HRT_API_CATCH
+}
+
+int32_t hrt_multi_devices(const hrt_multi* m) { return m ? (int32_t)m->devices.size() : 0; }
+int32_t hrt_multi_uses_rccl(const hrt_multi* m) { return m && m->use_rccl ? 1 : 0; }
+
+hrt_status hrt_multi_render(hrt_multi* m, const hrt_camera* cam, const hrt_params* pr, int32_t R, int32_t sample_first, int32_t sample_count,
+                            const float* resume_sums, float* out_sums, uint8_t* out_u8, hrt_stats* stats) {
+    HRT_API_TRY
+    if (!m || !cam) return fail(HRT_ERR_INVALID, "NULL argument");
+    hrt_status st = check_params(pr);
+    if (st != HRT_OK) return st;
+    if (R <= 0) return fail(HRT_ERR_INVALID, "rows_per_block must be positive");
+    if (sample_count < 0) sample_count = pr->samples - sample_first;
+    if (sample_first < 0 || sample_count < 0 || sample_first + sample_count > pr->samples) return fail(HRT_ERR_INVALID, "sample range outside [0, samples)");
+    const int G = (int)m->devices.size();
+    const int W = pr->width, H = pr->height, W3 = W * 3;
+    st = multi_reserve(m, W, H, R);
+    if (st != HRT_OK) return st;
+    const long long n_film = (long long)H * W3;
+    auto blocks_for = [&](long long n) { return (int)std::min<long long>((n + 255) / 256, (long long)m->scenes[0]->n_cus * 8); };
+
+    if (resume_sums) {   // a checkpoint's sums (film order) -> every rank's stripes
+        HIPCHK(hipSetDevice(m->devices[0]));
+        HIPCHK(hipMemcpyAsync(m->d_film, resume_sums, (size_t)n_film * sizeof(float), hipMemcpyHostToDevice, m->streams[0]));
+        HIPCHK(hipStreamSynchronize(m->streams[0]));
+        for (int g = 0; g < G; ++g) {
+            const int rows = hrt_stripe_rows(H, R, g, G);
+            if (!rows) continue;
+            HIPCHK(hipSetDevice(m->devices[g]));
+            float* src = m->d_film;
+            float* tmp = nullptr;
+            if (g != 0) {   // (rare path: through the host rather than a second collective)
+                HIPCHK(hipMalloc((void**)&tmp, (size_t)n_film * sizeof(float)));
+                HIPCHK(hipMemcpy(tmp, resume_sums, (size_t)n_film * sizeof(float), hipMemcpyHostToDevice));
+                src = tmp;
+            }
+            hipLaunchKernelGGL(k_restripe, dim3(blocks_for((long long)rows * W3)), dim3(256), 0, m->streams[g], src, m->d_accum[g], H, W3, R, G, g, rows);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(m->streams[g]));
+            if (tmp) (void)hipFree(tmp);
+        }
+    }
+
+    // ---- render: every device its stripes, concurrently (one host thread per device enqueues its ~100 launches)
+    std::vector<hrt_status> rst(G, HRT_OK);
+    std::vector<std::string> rerr(G);
+    if (sample_count > 0) {
+        auto work = [&](int g) {
+            if (hrt_stripe_rows(H, R, g, G) == 0) return;      // more ranks than row blocks: nothing to do here
+            rst[g] = hrt_render_stripes_accumulate_device(m->scenes[g], cam, pr, R, g, G, m->d_accum[g], sample_first, sample_count, m->streams[g]);
+            if (rst[g] != HRT_OK) rerr[g] = g_err;
+        };
+        std::vector<std::thread> threads;
+        for (int g = 1; g < G; ++g) threads.emplace_back(work, g);
+        work(0);
+        for (auto& t : threads) t.join();
+        for (int g = 0; g < G; ++g) if (rst[g] != HRT_OK) return fail(rst[g], "device " + std::to_string(m->devices[g]) + ": " + rerr[g]);
+    }
+    // ---- gather the device-resident stripes: equal (padded) shares, one ncclAllGather per communicator, grouped
+    if (m->use_rccl) {
+        const RcclApi& rccl = rccl_api();
+        NCCLCHK(rccl.GroupStart());
+        for (int g = 0; g < G; ++g) {
+            ncclResult_t r = rccl.AllGather(m->d_accum[g], m->d_gather[g], (size_t)m->share, ncclFloat, m->comms[g], m->streams[g]);
+            if (r != ncclSuccess) { (void)rccl.GroupEnd(); return fail_nccl(r, "ncclAllGather"); }
+        }
+        NCCLCHK(rccl.GroupEnd());
+    }
+    // ---- first device: film order, preview mean, tonemap, copies
+    HIPCHK(hipSetDevice(m->devices[0]));
+    hipStream_t s0 = m->streams[0];
+    hipLaunchKernelGGL(k_unstripe, dim3(blocks_for(n_film)), dim3(256), 0, s0, m->d_gather[0], m->d_film, H, W3, R, G, m->share);
+    HIPCHK(hipGetLastError());
+    if (out_sums) HIPCHK(hipMemcpyAsync(out_sums, m->d_film, (size_t)n_film * sizeof(float), hipMemcpyDeviceToHost, s0));
+    if (out_u8) {
+        const int s_done = sample_first + sample_count;
+        const float* src = m->d_film;                                  // the last pass divided (main.cpp:126): the sums are the means
+        if (s_done < pr->samples) {
+            hipLaunchKernelGGL(k_preview_mean, dim3(blocks_for(n_film)), dim3(256), 0, s0, m->d_film, m->d_mean, n_film, static_cast<float>(s_done > 0 ? s_done : 1));
+            src = m->d_mean;
+        }
+        hipLaunchKernelGGL(k_resolve, dim3(blocks_for((long long)W * H)), dim3(256), 0, s0, src, (long long)W * H, m->d_u8);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out_u8, m->d_u8, (size_t)W * H * 3, hipMemcpyDeviceToHost, s0));
+    }
+    for (int g = G - 1; g >= 0; --g) { HIPCHK(hipSetDevice(m->devices[g])); HIPCHK(hipStreamSynchronize(m->streams[g])); }
+    if (stats) {
+        hrt_stats total{};
+        for (int g = 0; g < G; ++g) {
+            hrt_stats one;
+            st = hrt_scene_stats(m->scenes[g], &one);
+            if (st != HRT_OK) return st;
+            total.rays += one.rays; total.samples += one.samples; total.box_tests += one.box_tests; total.tri_tests += one.tri_tests;
+            total.mesh_hits += one.mesh_hits; total.env_lookups += one.env_lookups; total.launches += one.launches;
+            total.traversal_box_tests += one.traversal_box_tests; total.traversal_tri_tests += one.traversal_tri_tests;
+            total.traversal_launches += one.traversal_launches;
+            if (one.kernel_ms > total.kernel_ms) total.kernel_ms = one.kernel_ms;          // the devices run side by side
+            if (one.traversal_ms > total.traversal_ms) total.traversal_ms = one.traversal_ms;
+        }
+        *stats = total;
+    }
+    return HRT_OK;
     HRT_API_CATCH
 }
 

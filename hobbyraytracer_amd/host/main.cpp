@@ -10,6 +10,7 @@
 //     --checkpoint FILE (store the accumulation buffer after every pass)   --resume (continue from that file)
 //     --max-passes K (stop after K passes; with --checkpoint the render can be resumed later)
 //     --dump-linear FILE.pfm (the fp32 linear film, bit for bit, next to the tonemapped image)
+//     --rccl (gather the film through an RCCL communicator even on one GPU; with --gpus N > 1 it always is)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,7 @@ int main(int argc, char** argv) {
         else if (a == "--assets") assets = next("--assets");
         else if (a == "--out") out = next("--out");
         else if (a == "--stats") opt.stats = true;
+        else if (a == "--rccl") opt.force_rccl = true;
         else if (a == "--make-assets") makeAssets = next("--make-assets");
         else if (a == "--progressive") opt.pass_samples = std::atoi(next("--progressive"));
         else if (a == "--checkpoint") opt.checkpoint = next("--checkpoint");
@@ -87,6 +89,7 @@ int main(int argc, char** argv) {
     std::shared_ptr<HittableList> world = scene.getScene();
 
     printElapsed(("Loaded scene: " + file + "!").c_str(), start);
+    const double load_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - start).count();
 
     if (opt.resume && opt.checkpoint.empty()) { std::cerr << "--resume needs --checkpoint FILE" << std::endl; return 2; }
     if (opt.pass_samples > 0) opt.on_pass = [&film](int) { film->outputFilm(); };   // preview image after every pass
@@ -104,11 +107,14 @@ int main(int argc, char** argv) {
     if (opt.stats || std::getenv("HRT_STATS")) {
         const double bytes = 32.0 * stats.box_tests + 36.0 * stats.tri_tests + 60.0 * stats.mesh_hits + 12.0 * stats.env_lookups +
                              12.0 * film->getFilm().width * film->getFilm().height;
+        // wall_s: the reference's own stopwatch (main.cpp:144,184): process start to after the image file is written
+        const double wall_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - start).count();
         std::printf("{\"rays\": %llu, \"samples\": %llu, \"box_tests\": %llu, \"tri_tests\": %llu, \"render_s\": %.6f, "
-                    "\"kernel_ms\": %.3f, \"mrays_per_s\": %.3f, \"msamples_per_s\": %.3f, \"algorithmic_gb_per_s\": %.3f}\n",
+                    "\"kernel_ms\": %.3f, \"mrays_per_s\": %.3f, \"msamples_per_s\": %.3f, \"algorithmic_gb_per_s\": %.3f, "
+                    "\"load_s\": %.6f, \"wall_s\": %.6f, \"gpus\": %d}\n",
                     (unsigned long long)stats.rays, (unsigned long long)stats.samples, (unsigned long long)stats.box_tests,
                     (unsigned long long)stats.tri_tests, seconds, stats.kernel_ms, stats.rays / seconds / 1e6,
-                    stats.samples / seconds / 1e6, stats.kernel_ms > 0 ? bytes / (stats.kernel_ms * 1e-3) / 1e9 : 0.0);
+                    stats.samples / seconds / 1e6, stats.kernel_ms > 0 ? bytes / (stats.kernel_ms * 1e-3) / 1e9 : 0.0, load_s, wall_s, opt.gpus);
     }
     printElapsed("Done!", start);
     return r;  // main.cpp:194 (1 = success)

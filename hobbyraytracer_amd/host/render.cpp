@@ -1,11 +1,12 @@
 // render.cpp — render() (main.cpp:81-140) on the GPU path.
 //
-// One host thread per GPU (the scene is replicated on every device, SURVEY.md
-// §8e); image rows are dealt to devices in interleaved blocks of
-// `rows_per_block` rows so that sky rows and geometry rows are shared out
-// evenly; the RNG is keyed by the absolute pixel index, so the result is
-// bit-identical for every device count.  Rank 0's device resolves the gathered
-// linear film to u8 (Film::tonemap + writeColour).
+// The scene is replicated on every device; image rows are dealt
+// to devices in interleaved blocks of `rows_per_block` rows so that sky rows
+// and geometry rows are shared out evenly; the RNG is keyed by the absolute
+// pixel index, so the result is bit-identical for every device count.  The
+// devices keep their stripes in their own memory; libhrt_hip.so's multi-GPU
+// session (hrt_multi_*) gathers them on the first device over RCCL / xGMI,
+// which also resolves the film to u8 (Film::tonemap + writeColour).
 #include "render.h"
 
 #include <atomic>
@@ -14,7 +15,6 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
-#include <thread>
 #include <vector>
 
 namespace hrthost {
@@ -26,8 +26,29 @@ struct Checkpoint {
     uint64_t seed;
     uint32_t quirks;
     int32_t max_depth;
+    uint64_t scene_hash;   // of the flattened scene and the camera: sums of another scene must not be continued
 };
-const char kMagic[8] = {'H', 'R', 'T', 'C', 'K', 'P', 'T', '1'};
+const char kMagic[8] = {'H', 'R', 'T', 'C', 'K', 'P', 'T', '2'};
+
+// FNV-1a over everything the kernels read of the scene (hrt_flat_scene's arrays) and the camera constants.
+uint64_t sceneHash(const hrt_flat_scene& f, const hrt_camera& cam) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t bytes) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < bytes; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    mix(&cam, sizeof(cam));
+    mix(f.prims, sizeof(hrt_prim) * f.n_prims); mix(f.materials, sizeof(hrt_material) * f.n_materials);
+    mix(f.textures, sizeof(hrt_texture) * f.n_textures); mix(f.meshes, sizeof(hrt_mesh) * f.n_meshes);
+    mix(f.tri_pos, sizeof(float) * 9 * f.n_tris); mix(f.tri_nrm, sizeof(float) * 9 * f.n_tris); mix(f.tri_uv, sizeof(float) * 6 * f.n_tris);
+    if (f.tri_ref_order) mix(f.tri_ref_order, sizeof(uint32_t) * f.n_tris);
+    mix(f.texels_u8, (size_t)f.n_texels_u8);
+    // (a 4096 x 2048 fp32 environment map is 100 MB: sample it -- every 61st float and the size)
+    mix(&f.n_texels_f32, sizeof(f.n_texels_f32));
+    for (uint64_t i = 0; i < f.n_texels_f32; i += 61) mix(f.texels_f32 + i, sizeof(float));
+    mix(&f.background_tex, sizeof(f.background_tex));
+    return h;
+}
 
 bool writeCheckpoint(const std::string& path, const Checkpoint& ck, const std::vector<float>& sums) {
     const std::string tmp = path + ".tmp";   // never leave a torn file under the real name
@@ -83,116 +104,83 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     pr.seed_lo = (uint32_t)opt.seed; pr.seed_hi = (uint32_t)(opt.seed >> 32);
     pr.flags = opt.stats ? HRT_FLAG_STATS : 0;
 
-    std::vector<hrt_scene*> scenes(G, nullptr);
-    for (int g = 0; g < G; ++g) {
-        st = hrt_scene_create(&flat, g, &scenes[g]);
-        if (st != HRT_OK) {
-            std::cerr << "hrt_scene_create(device " << g << "): " << hrt_status_str(st) << ": " << hrt_last_error() << std::endl;
-            for (hrt_scene* s : scenes) hrt_scene_destroy(s);
-            return st;
-        }
+    // The multi-GPU session: scene on every device, stripes accumulated in device memory, RCCL gather (hrt.h hrt_multi_*).
+    hrt_multi* multi = nullptr;
+    st = hrt_multi_create(&flat, G, nullptr, opt.force_rccl ? 1 : 0, &multi);
+    if (st != HRT_OK) {
+        std::cerr << "hrt_multi_create(" << G << " devices): " << hrt_status_str(st) << ": " << hrt_last_error() << std::endl;
+        return st;
     }
 
     std::cout << "\rPixels rendered: 0/" << numPixels << std::flush;  // main.cpp:100
     const auto t0 = std::chrono::high_resolution_clock::now();
 
     const int R = opt.rows_per_block;
-    std::vector<std::vector<float>> parts(G);
-    for (int g = 0; g < G; ++g) parts[g].assign((size_t)hrt_stripe_rows(f.height, R, g, G) * f.width * 3, 0.0f);
     std::vector<float>& lin = film->linear();     // what the film shows: the preview mean, at the end the final mean
-    std::vector<float> sums(lin.size(), 0.0f);     // whole-film accumulation buffer (absolute row order)
-    auto gather = [&]() {   // rank g's local row l is absolute row hrt_stripe_row_index(...)
-        for (int g = 0; g < G; ++g) {
-            const int rows = hrt_stripe_rows(f.height, R, g, G);
-            for (int l = 0; l < rows; ++l) {
-                const int row = hrt_stripe_row_index(f.height, R, g, G, l);
-                std::memcpy(&sums[(size_t)row * f.width * 3], &parts[g][(size_t)l * f.width * 3], (size_t)f.width * 3 * sizeof(float));
-            }
-        }
-    };
-    auto scatter = [&]() {
-        for (int g = 0; g < G; ++g) {
-            const int rows = hrt_stripe_rows(f.height, R, g, G);
-            for (int l = 0; l < rows; ++l) {
-                const int row = hrt_stripe_row_index(f.height, R, g, G, l);
-                std::memcpy(&parts[g][(size_t)l * f.width * 3], &sums[(size_t)row * f.width * 3], (size_t)f.width * 3 * sizeof(float));
-            }
-        }
-    };
-    auto cleanup = [&]() { for (hrt_scene* s : scenes) hrt_scene_destroy(s); };
+    std::vector<float> sums(lin.size(), 0.0f);     // whole-film accumulation buffer (film order), as gathered on the first device
+    auto cleanup = [&]() { hrt_multi_destroy(multi); };
 
     int s_done = 0;
+    bool have_resume = false;
     if (opt.resume) {
         Checkpoint ck;
         std::string why;
         if (!readCheckpoint(opt.checkpoint, ck, sums, why)) { std::cerr << "\nresume: " << why << std::endl; cleanup(); return HRT_ERR_IO; }
         if (ck.width != f.width || ck.height != f.height || ck.samples != f.samples || ck.seed != opt.seed || ck.quirks != opt.quirks ||
-            ck.max_depth != opt.max_depth || ck.next_sample < 0 || ck.next_sample > f.samples) {
-            std::cerr << "\nresume: " << opt.checkpoint << " belongs to a different render (film, samples, seed, quirks or depth differ)" << std::endl;
+            ck.max_depth != opt.max_depth || ck.next_sample < 0 || ck.next_sample > f.samples || ck.scene_hash != sceneHash(flat, cam)) {
+            std::cerr << "\nresume: " << opt.checkpoint << " belongs to a different render (scene, camera, film, samples, seed, quirks or depth differ)" << std::endl;
             cleanup();
             return HRT_ERR_INVALID;
         }
         s_done = ck.next_sample;
-        scatter();
+        have_resume = true;
         std::cout << "\rResumed at sample " << s_done << "/" << f.samples << std::endl;
     }
     const int pass = opt.pass_samples > 0 ? opt.pass_samples : f.samples;
     hrt_stats total{};
     int passes = 0;
+    bool resolved = false;
     while (s_done < f.samples && (opt.max_passes <= 0 || passes < opt.max_passes)) {
         ++passes;
         const int n = std::min(pass, f.samples - s_done);
-        std::vector<hrt_stats> pstats(G);
-        std::vector<hrt_status> pst(G, HRT_OK);
-        std::vector<std::string> perr(G);
-        auto work = [&](int g) {
-            pst[g] = hrt_render_stripes_accumulate(scenes[g], &cam, &pr, R, g, G, parts[g].data(), s_done, n, &pstats[g]);
-            if (pst[g] != HRT_OK) perr[g] = hrt_last_error();
-        };
-        std::vector<std::thread> threads;
-        for (int g = 1; g < G; ++g) threads.emplace_back(work, g);
-        work(0);
-        for (auto& t : threads) t.join();
-        double pass_kernel_ms = 0.0;
-        for (int g = 0; g < G; ++g) {
-            if (pst[g] != HRT_OK) {
-                std::cerr << "\nrender on device " << g << " failed: " << hrt_status_str(pst[g]) << ": " << perr[g] << std::endl;
-                cleanup();
-                return pst[g];
-            }
-            total.rays += pstats[g].rays; total.samples += pstats[g].samples; total.box_tests += pstats[g].box_tests;
-            total.tri_tests += pstats[g].tri_tests; total.mesh_hits += pstats[g].mesh_hits; total.env_lookups += pstats[g].env_lookups;
-            total.launches += pstats[g].launches; total.traversal_box_tests += pstats[g].traversal_box_tests;
-            total.traversal_tri_tests += pstats[g].traversal_tri_tests;
-            if (pstats[g].kernel_ms > pass_kernel_ms) pass_kernel_ms = pstats[g].kernel_ms;
+        hrt_stats ps{};
+        st = hrt_multi_render(multi, &cam, &pr, R, s_done, n, have_resume ? sums.data() : nullptr, sums.data(), film->getPixels(), &ps);
+        have_resume = false;
+        if (st != HRT_OK) {
+            std::cerr << "\nrender failed: " << hrt_status_str(st) << ": " << hrt_last_error() << std::endl;
+            cleanup();
+            return st;
         }
-        total.kernel_ms += pass_kernel_ms;
+        resolved = true;
+        total.rays += ps.rays; total.samples += ps.samples; total.box_tests += ps.box_tests; total.tri_tests += ps.tri_tests;
+        total.mesh_hits += ps.mesh_hits; total.env_lookups += ps.env_lookups; total.launches += ps.launches;
+        total.traversal_box_tests += ps.traversal_box_tests; total.traversal_tri_tests += ps.traversal_tri_tests;
+        total.kernel_ms += ps.kernel_ms;
         s_done += n;
-        gather();
         if (!opt.checkpoint.empty()) {
-            Checkpoint ck{f.width, f.height, f.samples, s_done, opt.seed, opt.quirks, opt.max_depth};
+            Checkpoint ck{f.width, f.height, f.samples, s_done, opt.seed, opt.quirks, opt.max_depth, sceneHash(flat, cam)};
             if (!writeCheckpoint(opt.checkpoint, ck, sums)) { std::cerr << "\ncannot write checkpoint " << opt.checkpoint << std::endl; cleanup(); return HRT_ERR_IO; }
         }
-        if (s_done < f.samples) {   // preview: mean of the samples so far
+        if (s_done < f.samples) {   // preview: mean of the samples so far (the u8 film was resolved on the device)
             const float k = static_cast<float>(s_done);
             for (size_t i = 0; i < lin.size(); ++i) lin[i] = sums[i] / k;
-            st = hrt_resolve_u8(scenes[0], lin.data(), numPixels, film->getPixels());
-            if (st != HRT_OK) { std::cerr << "\nresolve failed: " << hrt_last_error() << std::endl; cleanup(); return st; }
             std::cout << "\rSamples rendered: " << s_done << "/" << f.samples << std::flush;
             if (opt.on_pass) opt.on_pass(s_done);
         }
     }
     const auto t1 = std::chrono::high_resolution_clock::now();
     if (render_seconds) *render_seconds = std::chrono::duration<double>(t1 - t0).count();
-    if (s_done >= f.samples) lin = sums;           // the last pass divided (main.cpp:126): the sums are the means now
-    else if (passes == 0) {                        // nothing rendered in this call (resume of a stopped render with --max-passes 0 ...)
-        const float k = static_cast<float>(s_done > 0 ? s_done : 1);
+    st = HRT_OK;
+    if (s_done >= f.samples && resolved) lin = sums;   // the last pass divided (main.cpp:126): the sums are the means now
+    else if (!resolved) {                              // nothing rendered in this call (resume of a stopped render with --max-passes 0 ...)
+        hrt_stats none{};
+        st = hrt_multi_render(multi, &cam, &pr, R, s_done, 0, have_resume ? sums.data() : nullptr, nullptr, film->getPixels(), &none);
+        if (st != HRT_OK) std::cerr << "\nresolve failed: " << hrt_last_error() << std::endl;
+        const float k = static_cast<float>(s_done > 0 && s_done < f.samples ? s_done : 1);
         for (size_t i = 0; i < lin.size(); ++i) lin[i] = sums[i] / k;
     }
-    st = hrt_resolve_u8(scenes[0], lin.data(), numPixels, film->getPixels());
-    if (st != HRT_OK) std::cerr << "\nresolve failed: " << hrt_last_error() << std::endl;
     std::cout << "\rPixels rendered: " << numPixels << "/" << numPixels << std::flush << "\n";
-    for (hrt_scene* s : scenes) hrt_scene_destroy(s);
+    hrt_multi_destroy(multi);
     if (stats) *stats = total;
     return st;
 }

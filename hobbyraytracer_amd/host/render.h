@@ -13,6 +13,7 @@ namespace hrthost {
 struct RenderOptions {
     int gpus = 1;                       // image row blocks are interleaved over this many devices
     int rows_per_block = 8;
+    bool force_rccl = false;            // gather through an RCCL communicator even with one device (--rccl; tests)
     uint32_t quirks = HRT_QUIRKS_REFERENCE;
     uint64_t seed = 0;
     int max_depth = 50;                 // MAX_DEPTH (main.cpp:32)

@@ -30,11 +30,12 @@ class StripeLayout:
         return api.stripe_row_indices(self.height, self.rows_per_block, rank, self.n_ranks)
 
 
-def gather_film(tile, layout, dist=None, out=None, gathered=None):
+def gather_film(tile, layout, dist=None, out=None, gathered=None, force_collective=False):
     """tile: (max_rows, W, 3) tensor holding this rank's rows (rows beyond its share are padding).
-    Returns the (H, W, 3) film in row order (on every rank).  `dist` = torch.distributed when n_ranks > 1."""
+    Returns the (H, W, 3) film in row order (on every rank).  `dist` = torch.distributed when n_ranks > 1;
+    force_collective: run the all_gather with one rank too (exercises the RCCL path on a one-GPU box)."""
     import torch
-    if layout.n_ranks > 1:
+    if layout.n_ranks > 1 or (force_collective and dist is not None):
         if gathered is None:
             gathered = torch.empty((layout.n_ranks * layout.max_rows, layout.width, 3), dtype=tile.dtype, device=tile.device)
         dist.all_gather_into_tensor(gathered, tile)   # concatenation along dim 0 (the form gloo and RCCL both accept)

@@ -303,6 +303,28 @@ int32_t hrt_stripe_rows(int32_t height, int32_t rows_per_block, int32_t rank, in
 /* Absolute row index of local row `local` of rank's stripes; -1 if out of range. */
 int32_t hrt_stripe_row_index(int32_t height, int32_t rows_per_block, int32_t rank, int32_t n_ranks, int32_t local);
 
+/* ---- multi-GPU session -----------------------------------
+ * The reference's render() (main.cpp:81-140) has one parallel loop over all pixels of the film (main.cpp:111-135, no state
+ * shared between pixels).  Here the flattened scene is replicated on `n_devices` GPUs of THIS process (`devices` = their
+ * indices, NULL = 0..n-1), the film rows are dealt to them in interleaved blocks (hrt_stripe_rows) and every device keeps
+ * the running sums of its rows in its own memory.  With more than one device (or force_rccl != 0) the session owns an RCCL
+ * communicator per device (ncclCommInitAll) and hrt_multi_render gathers the device-resident stripes on the first device
+ * with one grouped ncclAllGather of equal, padded shares over xGMI; nothing but the finished film crosses PCIe. */
+typedef struct hrt_multi hrt_multi;
+hrt_status hrt_multi_create(const hrt_flat_scene* flat, int32_t n_devices, const int32_t* devices, int32_t force_rccl, hrt_multi** out);
+void hrt_multi_destroy(hrt_multi* m);
+int32_t hrt_multi_devices(const hrt_multi* m);
+int32_t hrt_multi_uses_rccl(const hrt_multi* m);
+/* Adds samples [sample_first, sample_first + sample_count) of params->samples on all devices at once (sample_count < 0: all that
+ * are left; 0: none, only gather what is there), gathers, and hands out (both optional, caller-owned HOST buffers):
+ *   out_sums  W*H*3 floats in film order: the running sums -- the means once the range has reached params->samples
+ *             (main.cpp:126); this plus the next sample index is the checkpoint of the render;
+ *   out_u8    W*H*3 bytes: Film::tonemap + writeColour (film.cpp:25-52) of sums / samples_done, resolved on the first device.
+ * resume_sums != NULL (W*H*3 floats, film order): the devices' sums are set from it first (continuing from a checkpoint,
+ * with any device count).  Blocking.  `stats`: summed over the devices; the two times are the slowest device's. */
+hrt_status hrt_multi_render(hrt_multi* m, const hrt_camera* cam, const hrt_params* params, int32_t rows_per_block, int32_t sample_first,
+                            int32_t sample_count, const float* resume_sums, float* out_sums, uint8_t* out_u8, hrt_stats* stats);
+
 /* Reads and clears the device-side counters of `scene` (synchronises its device). */
 hrt_status hrt_scene_stats(hrt_scene* scene, hrt_stats* stats);
 

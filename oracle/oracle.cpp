@@ -1030,4 +1030,25 @@ void oracle_quat_rotate_euler_deg(const float* euler_deg, const float* v, float*
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+// glm::reflect / glm::refract / glm::normalize as restated in csrc/hrt_glm.h (material.h:168,224-225), for the KATs against
+// independent float64 formulas (tests/test_oracle_kats.py): n vectors each, out 3 floats per vector
+void oracle_reflect(int64_t n, const float* I, const float* N, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        vec3 r = reflect(vec3(I[3 * i], I[3 * i + 1], I[3 * i + 2]), vec3(N[3 * i], N[3 * i + 1], N[3 * i + 2]));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+void oracle_refract(int64_t n, const float* I, const float* N, const float* eta, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        vec3 r = refract(vec3(I[3 * i], I[3 * i + 1], I[3 * i + 2]), vec3(N[3 * i], N[3 * i + 1], N[3 * i + 2]), eta[i]);
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+void oracle_normalize(int64_t n, const float* v, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        vec3 r = normalize(vec3(v[3 * i], v[3 * i + 1], v[3 * i + 2]));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+
 }  // extern "C"

@@ -149,3 +149,32 @@ def quat_rotate_euler_deg(euler_deg, v):
     out = np.empty(3, dtype=np.float32)
     _lib.oracle_quat_rotate_euler_deg(_p(_f32(euler_deg)), _p(_f32(v)), _p(out))
     return out
+
+
+_lib.oracle_reflect.argtypes = [C.c_int64, _fp, _fp, _fp]
+_lib.oracle_reflect.restype = None
+_lib.oracle_refract.argtypes = [C.c_int64, _fp, _fp, _fp, _fp]
+_lib.oracle_refract.restype = None
+_lib.oracle_normalize.argtypes = [C.c_int64, _fp, _fp]
+_lib.oracle_normalize.restype = None
+
+
+def reflect(i, n):
+    i, n = _f32(i), _f32(n)
+    out = np.empty_like(i)
+    _lib.oracle_reflect(len(i), _p(i), _p(n), _p(out))
+    return out
+
+
+def refract(i, n, eta):
+    i, n, eta = _f32(i), _f32(n), _f32(eta)
+    out = np.empty_like(i)
+    _lib.oracle_refract(len(i), _p(i), _p(n), _p(eta), _p(out))
+    return out
+
+
+def normalize(v):
+    v = _f32(v)
+    out = np.empty_like(v)
+    _lib.oracle_normalize(len(v), _p(v), _p(out))
+    return out

@@ -14,7 +14,7 @@ timeout -k 10 400 python3 bench.py > $out/bench_line.json 2> $out/bench.err || {
 echo "bench: $(cut -c1-200 $out/bench_line.json)"
 
 rm -rf $out/kt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/kt.log 2>&1 || { echo "kernel-trace failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cli-wall-clock > $out/kt.log 2>&1 || { echo "kernel-trace failed"; exit 1; }
 cp $out/kt/*/*_kernel_stats.csv $out/kernel_stats.csv
 echo "kernel stats done"
 

@@ -37,6 +37,18 @@ def assets(built, tmp_path_factory):
     return str(d)
 
 
+@pytest.fixture(scope="session")
+def assets_full(built, tmp_path_factory):
+    """The stand-ins at BASELINE's sizes (configs C4 / C5): teapot.obj ~6.3k triangles, marble_bust_01.obj ~100k triangles,
+    old_hall_4k.hdr 4096 x 2048.  GPU tests only (the CPU suite stays with the small `assets`)."""
+    from hobbyraytracer_amd import api
+    d = tmp_path_factory.mktemp("assets_full")
+    api.write_teapot_obj(str(d / "teapot.obj"), 1.0)
+    api.write_hall_hdr(str(d / "old_hall_4k.hdr"), 4096, 2048)
+    api.write_bust_obj(str(d / "marble_bust_01.obj"), 1.0)
+    return str(d)
+
+
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
 

@@ -145,3 +145,29 @@ def test_product_package_does_not_reference_the_oracle():
                     if re.search(r"liboracle|oracle_py|import oracle|from oracle|#include\s*[\"<][^\">]*oracle|dlopen\([^)]*oracle", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_stripe_partition_and_its_inverse_with_more_ranks_than_row_blocks(built):
+    """hrt_stripe_rows / hrt_stripe_row_index (the multi-GPU row partition) against the inverse map the gather kernels of
+    hrt_multi_render use (k_unstripe: block b = row / R belongs to rank b % G, local row (b / G) * R + row % R), including
+    partitions in which some ranks own nothing (G > number of row blocks: a 48-row film on 8 GPUs has 6 blocks of 8 rows)."""
+    import numpy as np
+    from hobbyraytracer_amd import api
+    r = np.random.default_rng(5)
+    cases = [(48, 8, 8), (5, 8, 4), (77, 8, 1), (640, 8, 8), (1080, 16, 3)] + [(int(r.integers(2, 300)), int(r.integers(1, 20)), int(r.integers(1, 12))) for _ in range(40)]
+    for H, R, G in cases:
+        rows = [api.stripe_rows(H, R, g, G) for g in range(G)]
+        assert sum(rows) == H and rows[0] == max(rows)                       # rank 0 owns the largest share (what the padded gather is sized by)
+        if G > (H + R - 1) // R:
+            assert rows[-1] == 0                                             # ranks without a block
+        seen = np.zeros(H, bool)
+        for g in range(G):
+            idx = api.stripe_row_indices(H, R, g, G)
+            assert len(idx) == rows[g] and (np.diff(idx) > 0).all()
+            for local, row in enumerate(idx):
+                b = row // R
+                assert b % G == g and (b // G) * R + (row - b * R) == local    # k_unstripe / k_restripe's index arithmetic
+                assert not seen[row]
+                seen[row] = True
+            assert api.stripe_row_index(H, R, g, G, rows[g]) == -1
+        assert seen.all()

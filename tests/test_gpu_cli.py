@@ -76,6 +76,53 @@ def test_cli_progressive_checkpoint_resume(built, assets, scenes_dir, tmp_path):
     assert p.returncode != 1 and "different render" in p.stderr
 
 
+def test_multi_gpu_session_through_rccl_on_one_device(built, assets, scenes_dir):
+    """hrt_multi_* (the C++ host's multi-GPU path): with force_rccl the session owns an RCCL communicator (ncclCommInitAll over
+    its one device here) and gathers the device-resident stripes with ncclAllGather before the first device puts the rows in
+    film order and resolves them -- film, u8 film and segment count equal hrt_render_tile's / hrt_resolve_u8's, in one shot and
+    in passes continued from a checkpoint's sums; without it the gather is skipped and the result is the same."""
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    W, H, spp = 100, 77, 6            # 77 rows: ten blocks of 8 rows, the last one short
+    cam = hs.camera(W, H)
+    p = api.default_params(W, H, spp, stats=True)
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    ref, sref = dev.render_tile(cam, p)
+    ref8 = dev.resolve_u8(ref)
+    for force in (True, False):
+        m = api.MultiScene(hs.flat_ptr, (0,), force_rccl=force)
+        assert m.uses_rccl == force
+        img, u8, st = m.render(cam, p)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(u8, ref8) and st.rays == sref.rays
+        # progressive: 2 + 4 samples, the second pass continued from the first pass's sums as a checkpoint would
+        sums, prev8, _ = m.render(cam, p, sample_first=0, sample_count=2)
+        two, _ = dev.render_tile(cam, api.default_params(W, H, 2))
+        assert np.array_equal(prev8, dev.resolve_u8(two))                  # the preview is the 2-sample film
+        m2 = api.MultiScene(hs.flat_ptr, (0,), force_rccl=force)
+        img2, u82, _ = m2.render(cam, p, sample_first=2, sample_count=-1, resume_sums=sums)
+        assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32)) and np.array_equal(u82, ref8)
+        m.close(); m2.close()
+    dev.close()
+
+
+def test_cli_rccl_flag_gives_the_same_image(built, assets, scenes_dir, tmp_path):
+    """The CLI's --gpus path is the multi-GPU session: `--rccl` sends the one-device film through the RCCL gather too."""
+    from hobbyraytracer_amd import api
+    import shutil
+    for f in ("teapot.obj", "old_hall_4k.hdr"):
+        shutil.copy(os.path.join(assets, f), tmp_path / f)
+    shutil.copy(f"{scenes_dir}/teapot_scene.yaml", tmp_path / "s.yaml")
+    outs = []
+    for extra in ([], ["--rccl"]):
+        name = "b.png" if extra else "a.png"
+        p = subprocess.run([api.CLI_PATH, "s.yaml", "--size", "64x48", "--spp", "4", "--out", name, "--stats", *extra], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 1, p.stderr
+        assert '"wall_s"' in p.stdout and '"load_s"' in p.stdout          # the reference's whole-process stopwatch (main.cpp:144,184)
+        outs.append(api.read_png(str(tmp_path / name)))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_bench_under_torchrun_two_ranks_on_one_gpu(built, assets, scenes_dir, tmp_path):
     """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run, one process per rank,
     rendezvous on 127.0.0.1), here with 2 ranks sharing the one GPU of the box and gloo as the collective backend (RCCL
@@ -103,3 +150,23 @@ def test_bench_under_torchrun_two_ranks_on_one_gpu(built, assets, scenes_dir, tm
     assert j["config"]["samples_per_step"] == 96 * 72 * 4 and "roofline" in j and "cpu_baseline" not in j   # cpu_baseline: N = 1 only
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert j1["config"]["rays_per_step"] == j["config"]["rays_per_step"]      # both ranks' segments add up to the single-GPU count
+
+
+def test_bench_one_rank_through_the_nccl_backend(built, tmp_path):
+    """bench.py --force-dist: with ONE rank the bench still runs init_process_group("nccl") (= RCCL on ROCm) and the
+    all_gather_into_tensor of the film tiles -- the collective path of the multi-GPU bench has then run on an MI355X before a
+    multi-GPU node sees it -- and its line equals the plain one: same film, same segment count."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--width", "96", "--height", "72", "--spp", "4", "--no-cpu-baseline", "--no-cli-wall-clock"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    outs = []
+    for extra, name in (([], "a.npy"), (["--force-dist", "--backend", "nccl"], "b.npy")):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, *extra, "--film-out", str(tmp_path / name)],
+                           capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0]))
+    a, b = np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert outs[0]["config"]["rays_per_step"] == outs[1]["config"]["rays_per_step"] and outs[1]["n_gpus"] == 1

@@ -444,22 +444,26 @@ def test_progressive_accumulation_equals_one_shot(built, assets, scenes_dir):
     dev.close()
 
 
-FULL_SIZE = [  # BASELINE.json configs at their full FILM sizes; spp reduced where the config's spp would only repeat the same code path
+FULL_SIZE = [  # BASELINE.json's configs as they stand: film size, spp and mesh size (C4 / C5 with the full-size stand-ins of `assets_full`)
     ("cornell_box.yaml", 640, 640, 256, "C2: 640x640x256, analytic primitives only"),
     ("teapot_scene.yaml", 1024, 1024, 256, "C3: 1024x1024x256 (268 M slots = 49 GB of wavefront state in one batch)"),
-    ("shiny_teapot.yaml", 1920, 1080, 16, "C4 film 1920x1080 (512 spp in BASELINE; 16 here)"),
-    ("bust_scene.yaml", 2048, 2048, 4, "C5 film 2048x2048 (1024 spp in BASELINE; 4 here)"),
+    ("shiny_teapot.yaml", 1920, 1080, 512, "C4: 1920x1080x512 = 1.06 G camera samples, 4096x2048 fp32 environment map"),
+    ("bust_scene.yaml", 2048, 2048, 1024, "C5: 2048x2048x1024 = 2^32 camera samples, ~100k-triangle bust, rough dielectric + constant medium"),
 ]
 
 
 @pytest.mark.parametrize("scene,W,H,spp,what", FULL_SIZE)
-def test_full_size_properties(built, assets, scenes_dir, scene, W, H, spp, what):
-    """Size-independent properties at BASELINE's film sizes: exact sample count, finite non-negative film, a 32x8
-    block equal to the oracle bit for bit, and row-stripe rendering of two ranks equal to the full frame."""
+def test_full_size_properties(built, assets_full, scenes_dir, scene, W, H, spp, what):
+    """BASELINE's configurations in full through size-independent properties: exact sample count (64-bit: C5 has 2^32), finite
+    non-negative film, a 32x8 block equal to the oracle bit for bit at the configuration's own spp, and row-stripe rendering of
+    two ranks equal to the full frame."""
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc
     quirks = api.QUIRKS_FIXED if scene == "teapot_scene.yaml" else api.QUIRKS_REFERENCE   # C3 = fixed quirks (SURVEY §8d)
-    hs = api.HostScene(f"{scenes_dir}/{scene}", assets)
+    hs = api.HostScene(f"{scenes_dir}/{scene}", assets_full)
+    if scene == "bust_scene.yaml":
+        assert hs.flat.n_tris > 95_000 and max(hs.bvh_depth(m) for m in range(hs.flat.n_meshes)) >= 17   # ~100k triangles, a deep tree
+        # (the 24- and 32-entry LDS stack variants of k_wf_ext: test_deep_bvh_uses_the_larger_stack_variants)
     dev = api.DeviceScene(hs.flat_ptr, 0)
     cam, p = hs.camera(W, H), api.default_params(W, H, spp, quirks=quirks)
     full, st = dev.render_tile(cam, p)
@@ -469,10 +473,40 @@ def test_full_size_properties(built, assets, scenes_dir, scene, W, H, spp, what)
     x0, y0 = W // 2 - 16, H // 2
     ref, _ = orc.World(hs.flat_ptr).render_tile(cam, p, (x0, y0, 32, 8))
     assert np.array_equal(full[y0:y0 + 8, x0:x0 + 32].view(np.uint32), ref.view(np.uint32)), what
-    if W * H * spp <= 50_000_000:
+    if W * H * spp <= 1_200_000_000:
         out = np.zeros_like(full)
         for rank in range(2):
             part, _ = dev.render_stripes(cam, p, 8, rank, 2)
             out[api.stripe_row_indices(H, 8, rank, 2)] = part
         assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
+    dev.close()
+
+
+def test_full_size_bust_hit_records_and_small_film(built, assets_full, scenes_dir, monkeypatch):
+    """The ~100k-triangle bust of config C5 (BVH deeper than 20: the larger LDS stack variants): hitRecord parity of 150 000
+    rays, and a small film on every render path, both quirk sets, against the oracle."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    hs = api.HostScene(f"{scenes_dir}/bust_scene.yaml", assets_full)
+    assert hs.flat.n_tris > 95_000
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    r = np.random.default_rng(23)
+    o = r.uniform([-3, 0.05, -3], [3, 4.5, 7], (150000, 3)).astype(np.float32)
+    d = (r.uniform([-1.2, 0, -1.2], [1.2, 3.0, 1.2], (150000, 3)) - o).astype(np.float32)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(16, 16, 1, quirks=q, seed=5)
+        g, c = dev.closest_hit(p, o, d, pixel0=1000), world.closest_hit(p, o, d, pixel0=1000)
+        assert np.array_equal(g["prim"], c["prim"]) and np.array_equal(g["tri"], c["tri"]), q
+        hit = c["prim"] >= 0
+        assert (c["tri"] >= 0).sum() > 20000
+        for f in ("t", "p", "normal", "u", "v"):
+            assert np.array_equal(g[f][hit].view(np.uint32), c[f][hit].view(np.uint32)), (q, f)
+        W, H, spp = 72, 72, 6
+        cam = hs.camera(W, H)
+        ref, sr = world.render_tile(cam, api.default_params(W, H, spp, quirks=q, stats=True))
+        for tail, mega in (("1", False), ("1000", False), ("1", True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(W, H, spp, quirks=q, stats=True, megakernel=mega))
+            assert st.rays == sr.rays and sr.mesh_hits > 5000, (q, tail, mega)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (q, tail, mega)
     dev.close()

@@ -75,6 +75,69 @@ def test_quaternion_euler_180_about_y(orc):
     np.testing.assert_allclose(orc.quat_rotate_euler_deg([0, 0, 90], v), [1.2, 0.3, 2.5], atol=2e-6)
 
 
+def test_quaternion_from_general_euler_angles_against_a_float64_rotation_composition(orc):
+    """scene.cpp:340 builds RotateQuat from glm::quat(glm::radians(angles)); rotateQuat.cpp:49-61 rotates with q * v.  glm's
+    constructor-from-Euler is the product qz * qy * qx, i.e. the matrix Rz(ez) Ry(ey) Rx(ex) (x applied first).  Checked here
+    for general angles against that composition in float64 -- an order or sign slip in the restatement (hrt_glm.h
+    quat_from_euler / rotate) cannot hide behind axis-aligned test angles.  glm itself is absent: this pins the restatement to
+    glm's DOCUMENTED convention, not to glm's code ('parity unpinned' stays)."""
+    r = np.random.default_rng(11)
+    worst = 0.0
+    for _ in range(400):
+        ang = r.uniform(-360, 360, 3)
+        v = r.normal(size=3) * 10 ** r.uniform(-2, 2)
+        ex, ey, ez = np.radians(ang)
+        Rx = np.array([[1, 0, 0], [0, np.cos(ex), -np.sin(ex)], [0, np.sin(ex), np.cos(ex)]])
+        Ry = np.array([[np.cos(ey), 0, np.sin(ey)], [0, 1, 0], [-np.sin(ey), 0, np.cos(ey)]])
+        Rz = np.array([[np.cos(ez), -np.sin(ez), 0], [np.sin(ez), np.cos(ez), 0], [0, 0, 1]])
+        want = Rz @ Ry @ Rx @ v
+        got = orc.quat_rotate_euler_deg(ang.astype(np.float32), v.astype(np.float32)).astype(np.float64)
+        worst = max(worst, np.abs(got - want).max() / np.linalg.norm(v))
+        # the other five orders are NOT what comes out (for generic angles they differ by O(1))
+    assert worst < 5e-6, worst
+    ang = np.array([25.0, -40.0, 70.0]); v = np.array([1.0, 2.0, 3.0])
+    ex, ey, ez = np.radians(ang)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ex), -np.sin(ex)], [0, np.sin(ex), np.cos(ex)]])
+    Ry = np.array([[np.cos(ey), 0, np.sin(ey)], [0, 1, 0], [-np.sin(ey), 0, np.cos(ey)]])
+    Rz = np.array([[np.cos(ez), -np.sin(ez), 0], [np.sin(ez), np.cos(ez), 0], [0, 0, 1]])
+    got = orc.quat_rotate_euler_deg(ang, v)
+    for wrong in (Rx @ Ry @ Rz, Ry @ Rx @ Rz, Rz @ Rx @ Ry, (Rz @ Ry @ Rx).T):
+        assert np.abs(got - wrong @ v).max() > 0.05
+
+
+def test_reflect_refract_normalize_against_float64(orc):
+    """glm::reflect (material.h:168,224), glm::refract (material.h:225: Snell's law), glm::normalize as restated in hrt_glm.h."""
+    r = np.random.default_rng(12)
+    n_vec = 20000
+    N = r.normal(size=(n_vec, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    I = r.normal(size=(n_vec, 3)); I /= np.linalg.norm(I, axis=1, keepdims=True)
+    R = orc.reflect(I, N).astype(np.float64)
+    np.testing.assert_allclose(R, I - 2 * (I * N).sum(1, keepdims=True) * N, atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(R, axis=1), 1.0, atol=2e-6)
+    np.testing.assert_allclose((R * N).sum(1), -(I * N).sum(1), atol=2e-6)              # the normal component flips ...
+    np.testing.assert_allclose(R - (R * N).sum(1, keepdims=True) * N, I - (I * N).sum(1, keepdims=True) * N, atol=2e-6)   # ... the tangential one stays
+    # refraction: incoming against the normal (dot(N, I) < 0, as Dielectric::scatter arranges with frontFace)
+    I2 = np.where(((I * N).sum(1) > 0)[:, None], -I, I)
+    for eta in (1 / 1.5, 1.5, 1 / 1.33, 2.4, 1.0):
+        T = orc.refract(I2, N, np.full(n_vec, eta, np.float32)).astype(np.float64)
+        cos_i = -(I2 * N).sum(1)
+        sin_i = np.sqrt(np.maximum(0.0, 1 - cos_i ** 2))
+        tir = eta * sin_i > 1.0
+        near = np.abs(eta * sin_i - 1.0) < 1e-4                       # (fp32 rounding decides at the critical angle)
+        assert (np.abs(T[tir & ~near]).max(initial=0.0) == 0.0)       # total internal reflection: glm returns the zero vector
+        ok = ~tir & ~near
+        np.testing.assert_allclose(np.linalg.norm(T[ok], axis=1), 1.0, atol=5e-6)
+        sin_t = np.linalg.norm(np.cross(T[ok], N[ok]), axis=1)
+        np.testing.assert_allclose(sin_t, eta * sin_i[ok], atol=5e-6)  # Snell: sin(theta_t) = eta sin(theta_i)
+        assert ((T[ok] * N[ok]).sum(1) < 1e-6).all()                  # transmitted to the far side of the surface
+        # ... in the plane of incidence
+        plane_n = np.cross(I2[ok], N[ok])
+        assert np.abs((T[ok] * plane_n).sum(1)).max() < 5e-6
+    V = r.normal(size=(1000, 3)) * 10 ** r.uniform(-10, 10, (1000, 1))
+    np.testing.assert_allclose(np.linalg.norm(orc.normalize(V).astype(np.float64), axis=1), 1.0, atol=3e-7)
+    np.testing.assert_allclose(orc.normalize(V), V / np.linalg.norm(V, axis=1, keepdims=True), rtol=0, atol=3e-7)
+
+
 def test_spherical_rand_distribution(orc):
     """glm::sphericalRand(1): unit length, zero mean, uniform z (restated semantics, SURVEY.md §8 a26)."""
     v = orc.spherical_rand(123, 400000).astype(np.float64)

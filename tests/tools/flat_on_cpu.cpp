@@ -73,7 +73,7 @@ void flatcpu_closest_hit(void* h, const hrt_params* pr, int64_t n, const float* 
         hh.prim = wh.prim; hh.tri = -1;
         if (wh.prim >= 0) {
             DRec rec;
-            world_rec(sc, wh, o, d, pr->quirks, rec);
+            world_rec(sc, wh, o, d, pr->quirks, t_min, rec);
             hh.t = rec.t; hh.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? wh.sub : -1; hh.front_face = rec.frontFace ? 1 : 0;
             hh.p[0] = rec.p.x; hh.p[1] = rec.p.y; hh.p[2] = rec.p.z;
             hh.normal[0] = rec.normal.x; hh.normal[1] = rec.normal.y; hh.normal[2] = rec.normal.z;

@@ -3,7 +3,7 @@
 tag=$1; shift
 export TMPDIR=/tmp
 rm -rf gpurun_out/kt_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/kt_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cli-wall-clock "$@" > gpurun_out/kt_$tag.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/kt_$tag/*/*_kernel_stats.csv")[0]

@@ -7,7 +7,7 @@ ctrs=$1; shift
 export TMPDIR=/tmp
 d=gpurun_out/pmc_${tag}_$(echo $ctrs | cksum | cut -d' ' -f1)
 rm -rf $d
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $d.log 2>&1
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli-wall-clock "$@" > $d.log 2>&1
 python3 - <<PY
 import csv,glob,json,os,collections,re
 fs=glob.glob("$d/*/*_counter_collection.csv")
