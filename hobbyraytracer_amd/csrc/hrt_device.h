@@ -920,7 +920,20 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     // tests/test_gpu_scenes.py::test_wrapper_chains_of_every_length pins it.
     vec3 d0 = d, d1 = d, d2 = d, d3 = d;
     static_assert(HRT_MAX_XFORMS == 4, "world_rec spells the wrapper chain out");
+#ifdef HRT_XF_FLAT   // the shape that came out wrong (tests/tools/repro_wrapper_chain.md): kept compilable for the reproducer only
+#ifdef HRT_XF_FLAT_INIT
+    vec3 dirs[HRT_MAX_XFORMS] = {d, d, d, d};
+#else
+    vec3 dirs[HRT_MAX_XFORMS];
+#endif
+#pragma unroll
+    for (int k = 0; k < HRT_MAX_XFORMS; ++k) {
+        if (k < n) { xf_apply(pr.xf[k], lo, ld, quirks); dirs[k] = ld; }
+    }
+    if (false) {
+#else
     if (n > 0) {
+#endif
         xf_apply(pr.xf[0], lo, ld, quirks); d0 = ld;
         if (n > 1) {
             xf_apply(pr.xf[1], lo, ld, quirks); d1 = ld;
@@ -953,7 +966,15 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
         rec.t = wh.t; rec.p = lo + (wh.t * ld); rec.normal = vec3(1, 0, 0); rec.frontFace = true; rec.u = 0.0f; rec.v = 0.0f;
     } else if (kind == HRT_PRIM_TRIANGLE) triangle_rec(pr.p, lo, ld, rec);
     else rect_rec(rect_axis(kind), pr.p, lo, ld, wh.t, rec);
+#ifdef HRT_XF_FLAT
+#pragma unroll
+    for (int k = HRT_MAX_XFORMS - 1; k >= 0; --k) {
+        if (k < n) xf_unapply(pr.xf[k], rec, dirs[k]);
+    }
+    if (false) {
+#else
     if (n > 0) {   // innermost wrapper first, nested for the same reason
+#endif
         if (n > 1) {
             if (n > 2) {
                 if (n > 3) xf_unapply(pr.xf[3], rec, d3);

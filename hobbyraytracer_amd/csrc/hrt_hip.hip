@@ -595,10 +595,11 @@ __device__ HRT_WAVE_FN void wf_ref_bfs(const RefMesh& rm, const hrt_params& pr, 
     bool alone = false;
     if (mine) {
         e0 = w.E0[q_mine]; e1 = w.E1[q_mine]; e2 = w.E2[q_mine];
-        alone = e1.x == 0.0f || e1.y == 0.0f || e1.z == 0.0f || rm.node_count >= (1u << 26);
+        // (a component below 1e-30 has no finite reciprocal for the level walk's box test: treated like zero)
+        alone = !(fabsf(e1.x) >= 1e-30f) || !(fabsf(e1.y) >= 1e-30f) || !(fabsf(e1.z) >= 1e-30f) || rm.node_count >= (1u << 26);
         const unsigned b = lane * 12u;
         wave_lds(sb, b + 0) = __float_as_int(e0.x); wave_lds(sb, b + 1) = __float_as_int(e0.y); wave_lds(sb, b + 2) = __float_as_int(e0.z);
-        wave_lds(sb, b + 3) = __float_as_int(e1.x); wave_lds(sb, b + 4) = __float_as_int(e1.y); wave_lds(sb, b + 5) = __float_as_int(e1.z);
+        wave_lds(sb, b + 3) = __float_as_int(1.0f / e1.x); wave_lds(sb, b + 4) = __float_as_int(1.0f / e1.y); wave_lds(sb, b + 5) = __float_as_int(1.0f / e1.z);
         wave_lds(sb, b + 6) = __float_as_int(e2.x); wave_lds(sb, b + 7) = __float_as_int(e2.y); wave_lds(sb, b + 8) = __float_as_int(e2.z);
         wave_lds(sb, b + 9) = __float_as_int(e2.w);
         // t_max for the level walk: what an accepted t can exceed the t_max it was compared with (a few ulp per candidate)
@@ -620,7 +621,7 @@ __device__ HRT_WAVE_FN void wf_ref_bfs(const RefMesh& rm, const hrt_params& pr, 
             unsigned r = 0, node = 0;
             bool pass = false;
             uint4 B; B.x = B.y = B.z = B.w = 0;
-            vec3 o, d;
+            vec3 o;
             if (valid) {
                 const unsigned item = (unsigned)wave_lds(sb, cur + b + lane);
                 r = item >> 26; node = item & 0x3ffffffu;
@@ -628,11 +629,16 @@ __device__ HRT_WAVE_FN void wf_ref_bfs(const RefMesh& rm, const hrt_params& pr, 
                 B = rm.nodes[2 * node + 1];
                 const unsigned rb = r * 12u;
                 o = vec3(__int_as_float(wave_lds(sb, rb + 0)), __int_as_float(wave_lds(sb, rb + 1)), __int_as_float(wave_lds(sb, rb + 2)));
-                d = vec3(__int_as_float(wave_lds(sb, rb + 3)), __int_as_float(wave_lds(sb, rb + 4)), __int_as_float(wave_lds(sb, rb + 5)));
-                float4 bmn, bmx;
-                bmn.x = __uint_as_float(A.x); bmn.y = __uint_as_float(A.y); bmn.z = __uint_as_float(A.z); bmn.w = 0.0f;
-                bmx.x = __uint_as_float(B.x); bmx.y = __uint_as_float(B.y); bmx.z = __uint_as_float(B.z); bmx.w = 0.0f;
-                pass = accept_box(bmn, bmx, o, d, pr.t_min, __int_as_float(wave_lds(sb, rb + 10)));
+                // The level walk only has to reach every node the reference's test (aabb.h:26-39: six IEEE divisions) would let
+                // through with the ray's first t_max; the exact tests come in the fold.  So: (b - o) * (1 / d) -- within 2 ulp of
+                // the quotient -- and a slack of 3e-7 of the two ends on the comparison.
+                const float ix = __int_as_float(wave_lds(sb, rb + 3)), iy = __int_as_float(wave_lds(sb, rb + 4)), iz = __int_as_float(wave_lds(sb, rb + 5));
+                const float ax = (__uint_as_float(A.x) - o.x) * ix, bx = (__uint_as_float(B.x) - o.x) * ix;
+                const float ay = (__uint_as_float(A.y) - o.y) * iy, by = (__uint_as_float(B.y) - o.y) * iy;
+                const float az = (__uint_as_float(A.z) - o.z) * iz, bz = (__uint_as_float(B.z) - o.z) * iz;
+                const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), pr.t_min));
+                const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), __int_as_float(wave_lds(sb, rb + 10))));
+                pass = t_out - t_in >= -3e-7f * (fabsf(t_out) + fabsf(t_in)) - 1e-37f;
             }
             const bool inner = pass && (B.w & 0x80000000u);
             const unsigned long long mi = __ballot(inner);
