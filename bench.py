@@ -220,8 +220,9 @@ def main():
                 except Exception:
                     pass
         # issue-side figures of the same kernel from the newest committed PMC profile of this workload (rocprofv3 --pmc passes,
-        # profiles/collect.sh): VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles); lane utilisation =
-        # SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4) -- as VERDICT r1 prescribes; wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES
+        # profiles/collect.sh), per frame: VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles =
+        # GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+        # (r01_v4: 0.32 for k_wf_ext, 0.57 for k_wf_shade, the figures VERDICT r1 quotes); wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES
         issue = None
         if traffic is not None:
             import glob
@@ -231,10 +232,10 @@ def main():
                     g = lambda c: float(pk[c]["sum_over_one_frame"])
                     cyc = g("GRBM_GUI_ACTIVE") if "GRBM_GUI_ACTIVE" in pk else None
                     issue = {"profile": os.path.relpath(os.path.dirname(pf), ROOT),
-                             "lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * 4.0 * g("SQ_ACTIVE_INST_VALU")), 4),
+                             "lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4),
                              "wait_share": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4)}
                     if cyc:
-                        issue["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * cyc), 4)
+                        issue["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * cyc / 8.0), 4)
                     break
                 except Exception:
                     continue

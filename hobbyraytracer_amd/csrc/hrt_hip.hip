@@ -1630,6 +1630,13 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     *out = nullptr;
     hrt_status st = validate(f);
     if (st != HRT_OK) return st;
+    // the reference's own tree of every mesh, for the rays that must walk it (hrt_device.h ref_walk); part of the validation:
+    // tri_ref_order must be the depth-first code of such a tree (checked before any device is touched)
+    RefTree ref;
+    {
+        std::string why;
+        if (!pack_ref_tree(f, ref, &why)) return fail(HRT_ERR_INVALID, why);
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(HRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -1662,12 +1669,6 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     uint4* d_nodes; float4* d_grids;
     UP(d_nodes, qn.data(), qn.size() * sizeof(uint32_t));
     UP(d_grids, grids.data(), grids.size() * sizeof(float));
-    // the reference's own tree of every mesh, for the rays that must walk it (hrt_device.h ref_walk)
-    RefTree ref;
-    {
-        std::string why;
-        if (!pack_ref_tree(f, ref, &why)) { hrt_scene_destroy(sc); return fail(HRT_ERR_INVALID, why); }
-    }
     uint4 *d_rnodes, *d_rmesh; float4* d_rtris;
     UP(d_rnodes, ref.nodes.data(), ref.nodes.size() * sizeof(uint32_t));
     UP(d_rtris, ref.tris.data(), ref.tris.size() * sizeof(float));

@@ -221,9 +221,18 @@ void Mesh::flatten(FlatBuilder& fb) const {
 // the only format the sample scenes use — is parsed here with the same
 // observable result: polygons are fan-triangulated, v -> 1 - v (FlipUVs), no
 // normals are generated (missing normals become (0,0,0): mesh.cpp:83-90, Q-9),
-// missing UVs become (0,0) (mesh.cpp:92-99).  Deviation: a multi-object OBJ is
-// read as ONE mesh with correct indices (the reference appends per-aiMesh
-// indices without rebasing them, Q-8, which scrambles such files).
+// missing UVs become (0,0) (mesh.cpp:92-99).
+// Q-8 (mesh.cpp:111-114): the reference appends every aiMesh's face indices to one global list WITHOUT adding the
+// number of vertices already there.  Assimp's OBJ importer makes one aiMesh per object / group / material run that has
+// faces and, without aiProcess_JoinIdenticalVertices, one vertex per face corner, so sub-mesh k's indices are
+// 0 .. 3 F_k - 1: its F_k triangles come out as copies of the FIRST F_k triangles of the whole file.  That is the
+// default here too (Mesh::objIndexQuirk, SURVEY 8.1: "default = reference"); single-object files -- every asset this
+// repository generates -- are not affected.  Switch: HRT_OBJ_INDICES=rebased in the environment, or the CLI's
+// --obj-indices rebased, read the file as one mesh with correct indices.
+bool Mesh::objIndexQuirk() {
+    const char* e = std::getenv("HRT_OBJ_INDICES");
+    return !(e && std::string(e) == "rebased");
+}
 bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& err) {
     std::ifstream f(path);
     if (!f) { err = "Unable to open file \"" + path + "\"."; return false; }
@@ -234,6 +243,8 @@ bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& e
     std::string line;
     struct Idx { int v, t, n; };
     std::vector<Idx> face;
+    std::vector<size_t> subMeshStart;   // first triangle of every aiMesh Assimp would make (object / group / material runs with faces)
+    bool newRun = true;
     int lineNo = 0;
     while (std::getline(f, line)) {
         ++lineNo;
@@ -288,6 +299,7 @@ bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& e
                 face.push_back(ix);
             }
             if (face.size() < 3) continue;  // points / lines are dropped by Triangulate
+            if (newRun) { subMeshStart.push_back(out.pos.size() / 9); newRun = false; }
             for (size_t k = 1; k + 1 < face.size(); ++k) {
                 const Idx tri[3] = {face[0], face[k], face[k + 1]};
                 for (const Idx& ix : tri) {
@@ -299,8 +311,23 @@ bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& e
                 }
             }
         }
+        else if ((s[0] == 'o' || s[0] == 'g') && (s[1] == ' ' || s[1] == '\t' || s[1] == 0)) newRun = true;
+        else if (std::strncmp(s, "usemtl", 6) == 0 && (s[6] == ' ' || s[6] == '\t')) newRun = true;
     }
     if (out.pos.empty()) { err = "OBJ: file contains no faces: " + path; return false; }
+    if (objIndexQuirk() && subMeshStart.size() > 1) {   // Q-8, see above
+        const TriangleSoup all = out;
+        const size_t total = all.pos.size() / 9;
+        for (size_t m = 1; m < subMeshStart.size(); ++m) {
+            const size_t first = subMeshStart[m], end = m + 1 < subMeshStart.size() ? subMeshStart[m + 1] : total;
+            for (size_t j = first; j < end; ++j) {       // triangle j - first of this sub-mesh <- triangle j - first of the file
+                const size_t src = j - first;
+                std::copy(all.pos.begin() + 9 * src, all.pos.begin() + 9 * src + 9, out.pos.begin() + 9 * j);
+                std::copy(all.nrm.begin() + 9 * src, all.nrm.begin() + 9 * src + 9, out.nrm.begin() + 9 * j);
+                std::copy(all.uv.begin() + 6 * src, all.uv.begin() + 6 * src + 6, out.uv.begin() + 6 * j);
+            }
+        }
+    }
     return true;
 }
 

@@ -289,6 +289,9 @@ public:
 private:
     // The importer seam (mesh.cpp:53-120 calls Assimp with Triangulate|FlipUVs).
     static bool importFile(const std::string& path, TriangleSoup& out, std::string& err);
+    // Q-8 (mesh.cpp:111-114, un-rebased indices of multi-mesh files): true = the reference's behaviour (default);
+    // HRT_OBJ_INDICES=rebased in the environment turns it off.
+    static bool objIndexQuirk();
     TriangleSoup soup;
     std::shared_ptr<BVHNode> tree;
     std::shared_ptr<Material> matPtr;

@@ -171,3 +171,38 @@ def test_stripe_partition_and_its_inverse_with_more_ranks_than_row_blocks(built)
                 seen[row] = True
             assert api.stripe_row_index(H, R, g, G, rows[g]) == -1
         assert seen.all()
+
+
+def test_scene_create_refuses_bad_reference_order_codes_and_deep_checkers_without_a_gpu(built, assets, scenes_dir):
+    """hrt_scene_create validates before it touches a device (so this runs on the CPU-only box: a good scene gets as far as
+    HRT_ERR_NO_DEVICE): tri_ref_order must be the depth-first code of a median-split tree -- the reference's own BVH is derived
+    from it for the rays that walk it (hrt_pack.h pack_ref_tree) --, and checkered textures may nest 4 deep at most."""
+    import copy
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    def status_of(flat):
+        try:
+            api.DeviceScene(flat, 0).close()
+            return api.HRT_OK
+        except api.HrtError as e:
+            return e.status
+    good = status_of(hs.flat_ptr)
+    if good == api.HRT_OK:
+        pytest.skip("a GPU is present: the no-device ordering is what this test is about")
+    assert good == api.HRT_ERR_NO_DEVICE
+    flat = api.FlatScene()
+    C.memmove(C.byref(flat), hs.flat_ptr, C.sizeof(api.FlatScene))
+    n = flat.n_tris
+    codes = (C.c_uint32 * n)(*[flat.tri_ref_order[i] for i in range(n)])
+    codes[7] = 12345678
+    flat.tri_ref_order = C.cast(codes, C.POINTER(C.c_uint32))
+    assert status_of(flat) == api.HRT_ERR_INVALID
+    codes[7] = codes[8]                                                  # a code used twice
+    assert status_of(flat) == api.HRT_ERR_INVALID
+    # a cyclic checker
+    C.memmove(C.byref(flat), hs.flat_ptr, C.sizeof(api.FlatScene))
+    nt = flat.n_textures
+    texs = (api.Texture * (nt + 1))(*[flat.textures[i] for i in range(nt)])
+    texs[nt].kind = api.TEX_CHECKER; texs[nt].even = nt; texs[nt].odd = 0
+    flat.textures = C.cast(texs, C.POINTER(api.Texture)); flat.n_textures = nt + 1
+    assert status_of(flat) == api.HRT_ERR_UNSUPPORTED

@@ -283,3 +283,34 @@ def test_film_size_is_bounded_before_it_is_allocated(built, tmp_path):
     with pytest.raises(api.HrtError) as e:
         api.HostScene(str(tmp_path / "big.yaml"), str(tmp_path))
     assert "2^30" in str(e.value)
+
+
+def test_q8_multi_object_obj_keeps_the_reference_index_bug_by_default(built, tmp_path, monkeypatch):
+    """Q-8 (mesh.cpp:111-114): the reference appends each aiMesh's face indices without rebasing them; Assimp makes one aiMesh per
+    object / group / material run and (without JoinIdenticalVertices) one vertex per face corner, so the triangles of every
+    later sub-mesh come out as copies of the FIRST triangles of the file.  Default = that behaviour; HRT_OBJ_INDICES=rebased
+    (CLI: --obj-indices rebased) reads the file correctly."""
+    from hobbyraytracer_amd import api
+    (tmp_path / "two.obj").write_text(
+        "o first\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 2//1 4//1 3//1\n"
+        "o second\nv 5 5 5\nv 6 5 5\nv 5 6 5\nf 5//1 6//1 7//1\n"
+        "usemtl other\nv 9 9 9\nv 10 9 9\nv 9 10 9\nf 8//1 9//1 10//1\n")
+    (tmp_path / "s.yaml").write_text(
+        "film:\n    width: 8\n    height: 8\n    samples: 1\n    output: o.png\n"
+        "camera:\n    position: [0, 0, 5]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 40\n    aperture: 0\n    focal_distance: 5\n    background: [0.5, 0.5, 0.5]\n"
+        "materials:\n  - name: m\n    type: lambertian\n    albedo: [0.5, 0.5, 0.5]\n"
+        "objects:\n  - type: mesh\n    path: two.obj\n    material: m\n")
+
+    def tris():
+        hs = api.HostScene(str(tmp_path / "s.yaml"), str(tmp_path))
+        pos = hs.mesh_arrays(0)[0].reshape(-1, 9)
+        return sorted(map(tuple, np.round(pos, 3).tolist()))
+    quirk = tris()
+    assert len(quirk) == 4
+    # sub-mesh "second" (1 triangle) and the usemtl run (1 triangle) are both copies of the file's first triangle
+    first = (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0)
+    assert quirk.count(first) == 3 and not any(5.0 in t or 9.0 in t for t in quirk)
+    monkeypatch.setenv("HRT_OBJ_INDICES", "rebased")
+    fixed = tris()
+    assert len(fixed) == 4 and fixed.count(first) == 1
+    assert (5.0, 5.0, 5.0, 6.0, 5.0, 5.0, 5.0, 6.0, 5.0) in fixed and (9.0, 9.0, 9.0, 10.0, 9.0, 9.0, 9.0, 10.0, 9.0) in fixed
