@@ -31,7 +31,7 @@ TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_ENV = range(4)
 MAX_XFORMS = 4
 Q1_ROTQ_NORMALIZE, Q2_TRI_NO_TMIN, Q3_TRI_NO_FACE, Q4_SHEAR_FROM_ORIGIN = 1, 2, 4, 8
 QUIRKS_REFERENCE, QUIRKS_FIXED = 0xF, 0x0
-FLAG_STATS, FLAG_MEGAKERNEL, FLAG_TIMING = 1, 2, 4
+FLAG_STATS, FLAG_MEGAKERNEL, FLAG_TIMING, FLAG_THIN_LENS = 1, 2, 4, 8
 
 
 # ---------------------------------------------------------------- structs (hrt.h)
@@ -85,7 +85,8 @@ class FlatScene(C.Structure):
 
 
 class Camera(C.Structure):
-    _fields_ = [("origin", C.c_float * 3), ("lower_left", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3)]
+    _fields_ = [("origin", C.c_float * 3), ("lower_left", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("lens_u", C.c_float * 3), ("lens_v", C.c_float * 3), ("lens_radius", C.c_float)]
 
 
 class Params(C.Structure):
@@ -221,14 +222,16 @@ def _ptr(a, t=_fp):
 
 
 # ---------------------------------------------------------------- host side
-def default_params(width, height, samples, quirks=QUIRKS_REFERENCE, seed=0, max_depth=50, stats=False, megakernel=False, timing=False):
+def default_params(width, height, samples, quirks=QUIRKS_REFERENCE, seed=0, max_depth=50, stats=False, megakernel=False, timing=False,
+                   thin_lens=False):
     p = Params()
     _host.hrt_default_params(C.byref(p), width, height, samples)
     p.quirks = quirks
     p.seed_lo = seed & 0xFFFFFFFF
     p.seed_hi = (seed >> 32) & 0xFFFFFFFF
     p.max_depth = max_depth
-    p.flags = (FLAG_STATS if stats else 0) | (FLAG_MEGAKERNEL if megakernel else 0) | (FLAG_TIMING if timing else 0)
+    p.flags = (FLAG_STATS if stats else 0) | (FLAG_MEGAKERNEL if megakernel else 0) | (FLAG_TIMING if timing else 0) | \
+              (FLAG_THIN_LENS if thin_lens else 0)
     return p
 
 

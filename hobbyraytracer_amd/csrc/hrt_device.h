@@ -1119,8 +1119,15 @@ __device__ inline void path_begin(const hrt_camera& cam, const hrt_params& pr, i
     const int y = pr.height - py;     // main.cpp:116 (H - pIdx / W), Q-10
     const float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (pr.width - 1);
     const float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (pr.height - 1);
-    ps.o = c_origin;
-    ps.d = c_llc + u * c_hor + v * c_ver - c_origin;
+    vec3 offset(0.0f);                                   // camera.h:34-35: the reference's lens offset is 0 ...
+    if (pr.flags & HRT_FLAG_THIN_LENS) {                 // ... unless the commented-out circularRand(lensRadius) is asked back
+        const u32x4 l = rng_draw(ctx, RNG_LENS, 0);
+        float rx, ry;
+        circular_rand(l.x, cam.lens_radius, rx, ry);
+        offset = vec3(cam.lens_u[0], cam.lens_u[1], cam.lens_u[2]) * rx + vec3(cam.lens_v[0], cam.lens_v[1], cam.lens_v[2]) * ry;
+    }
+    ps.o = c_origin + offset;
+    ps.d = c_llc + u * c_hor + v * c_ver - c_origin - offset;
     ps.atten = vec3(1.0f); ps.result = vec3(0.0f); ps.bounce = 0;
 }
 

@@ -27,7 +27,8 @@ enum rng_purpose : uint32_t {
     RNG_SCATTER = 1,  // Material::scatter draws of one bounce
     RNG_MEDIUM = 2,   // constantMedium.cpp:25, aux = prim index
     RNG_BALL = 3,     // glm::ballRand rejection loop, aux = attempt
-    RNG_BUILD = 4     // bvh.cpp:10 axis choice (oracle tree build only)
+    RNG_BUILD = 4,    // bvh.cpp:10 axis choice (oracle tree build only)
+    RNG_LENS = 5      // camera.h:34 glm::circularRand(lensRadius), HRT_FLAG_THIN_LENS only (bounce field = 0)
 };
 
 HRT_HD void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
@@ -83,6 +84,14 @@ HRT_HD vec3 spherical_rand(uint32_t u_theta, uint32_t u_z) {
     float y = sp * st;
     float z = cp;
     return vec3(x, y, z);
+}
+
+// glm::circularRand(R): a = linearRand(0, 2 pi); (cos a, sin a) * R   -- a point ON the circle (gtc/random.inl)
+HRT_HD void circular_rand(uint32_t u_a, float radius, float& x, float& y) {
+    float a = linear_rand(u_a, 0.0f, 6.283185307179586476925286766559f);
+    float s, c;
+    gsincos(a, s, c);
+    x = c * radius; y = s * radius;
 }
 
 // glm::ballRand(1): rejection on linearRand(vec3(-1), vec3(1)) until length <= 1.

@@ -352,6 +352,9 @@ hrt_camera Camera::flatten() const {
     c.lower_left[0] = lowerLeftCorner.x; c.lower_left[1] = lowerLeftCorner.y; c.lower_left[2] = lowerLeftCorner.z;
     c.horizontal[0] = horizontal.x; c.horizontal[1] = horizontal.y; c.horizontal[2] = horizontal.z;
     c.vertical[0] = vertical.x; c.vertical[1] = vertical.y; c.vertical[2] = vertical.z;
+    c.lens_u[0] = u.x; c.lens_u[1] = u.y; c.lens_u[2] = u.z;
+    c.lens_v[0] = v.x; c.lens_v[1] = v.y; c.lens_v[2] = v.z;
+    c.lens_radius = lensRadius;
     return c;
 }
 

@@ -11,6 +11,7 @@
 //     --max-passes K (stop after K passes; with --checkpoint the render can be resumed later)
 //     --dump-linear FILE.pfm (the fp32 linear film, bit for bit, next to the tonemapped image)
 //     --obj-indices reference|rebased (multi-object OBJ files: the reference's un-rebased face indices, mesh.cpp:111-114, or correct ones)
+//     --lens (thin-lens sampling with the scene's `aperture`: camera.h:34's commented-out circularRand(lensRadius); off = the reference)
 //     --rccl (gather the film through an RCCL communicator even on one GPU; with --gpus N > 1 it always is)
 #include <chrono>
 #include <cstdio>
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next("--out");
         else if (a == "--stats") opt.stats = true;
         else if (a == "--rccl") opt.force_rccl = true;
+        else if (a == "--lens") opt.thin_lens = true;
         else if (a == "--obj-indices") { std::string v = next("--obj-indices"); setenv("HRT_OBJ_INDICES", v == "rebased" ? "rebased" : "reference", 1); }
         else if (a == "--make-assets") makeAssets = next("--make-assets");
         else if (a == "--progressive") opt.pass_samples = std::atoi(next("--progressive"));

@@ -102,7 +102,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     pr.width = f.width; pr.height = f.height; pr.samples = f.samples;
     pr.max_depth = opt.max_depth; pr.t_min = 0.001f; pr.quirks = opt.quirks;
     pr.seed_lo = (uint32_t)opt.seed; pr.seed_hi = (uint32_t)(opt.seed >> 32);
-    pr.flags = opt.stats ? HRT_FLAG_STATS : 0;
+    pr.flags = (opt.stats ? HRT_FLAG_STATS : 0) | (opt.thin_lens ? HRT_FLAG_THIN_LENS : 0);
 
     // The multi-GPU session: scene on every device, stripes accumulated in device memory, RCCL gather (hrt.h hrt_multi_*).
     hrt_multi* multi = nullptr;

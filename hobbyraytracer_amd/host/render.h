@@ -13,6 +13,7 @@ namespace hrthost {
 struct RenderOptions {
     int gpus = 1;                       // image row blocks are interleaved over this many devices
     int rows_per_block = 8;
+    bool thin_lens = false;             // sample the lens as camera.h:34's commented-out circularRand(lensRadius) would (--lens)
     bool force_rccl = false;            // gather through an RCCL communicator even with one device (--rccl; tests)
     uint32_t quirks = HRT_QUIRKS_REFERENCE;
     uint64_t seed = 0;

@@ -184,13 +184,18 @@ typedef struct hrt_flat_scene {
     int32_t _pad;
 } hrt_flat_scene;
 
-/* camera.h:41-45 — the four constants Camera::getRay uses (lens offset is
- * hard-wired to 0 in the reference, camera.h:34-35). */
+/* camera.h:41-48 — the constants of Camera::getRay.  The reference hard-wires the lens offset to 0 (camera.h:34:
+ * `rd = {0,0,0}; // glm::circularRand(lensRadius)`, "TODO: Add back in randomness"), so lens_u / lens_v / lens_radius are only
+ * read with HRT_FLAG_THIN_LENS, which puts that commented-out call back: rd = circularRand(lensRadius) -- a point ON the circle
+ * of that radius, as glm defines it --, offset = u * rd.x + v * rd.y (camera.h:35-37). */
 typedef struct hrt_camera {
     float origin[3];
     float lower_left[3];
     float horizontal[3];
     float vertical[3];
+    float lens_u[3];        /* camera.h:20  u = normalize(cross(up, w)) */
+    float lens_v[3];        /* camera.h:21  v = cross(w, u)             */
+    float lens_radius;      /* camera.h:26  aperture / 2                */
 } hrt_camera;
 
 /* Quirk switches.  A set bit = reference behaviour. */
@@ -219,8 +224,9 @@ enum {
                                   build of the kernels; rays and samples are always counted) */
     HRT_FLAG_MEGAKERNEL = 1u << 1, /* render with the single persistent-lanes kernel (k_pathtrace) instead of the
                                   default wavefront pipeline (k_wf_*); results are bit-identical */
-    HRT_FLAG_TIMING = 1u << 2  /* wavefront pipeline: also time the traversal kernel's launches with HIP events
+    HRT_FLAG_TIMING = 1u << 2, /* wavefront pipeline: also time the traversal kernel's launches with HIP events
                                   (hrt_stats.traversal_ms) */
+    HRT_FLAG_THIN_LENS = 1u << 3 /* sample the lens as camera.h:34's commented-out call would (see hrt_camera); off = the reference */
 };
 
 typedef struct hrt_rect { int32_t x0, y0, w, h; } hrt_rect;   /* y0 = row index from the TOP (pIdx / W) */

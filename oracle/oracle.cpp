@@ -818,12 +818,18 @@ static vec3 rayColour(ray r, const World& w, const hrt_flat_scene* fs, int max_d
 }
 
 // camera.h:29-39
-static ray getRay(const hrt_camera* c, float s, float t) {
+static ray getRay(const hrt_camera* c, float s, float t, bool thin_lens) {
     vec3 origin(c->origin[0], c->origin[1], c->origin[2]);
     vec3 llc(c->lower_left[0], c->lower_left[1], c->lower_left[2]);
     vec3 hor(c->horizontal[0], c->horizontal[1], c->horizontal[2]);
     vec3 ver(c->vertical[0], c->vertical[1], c->vertical[2]);
-    vec3 offset(0.0f);
+    vec3 offset(0.0f);                     // camera.h:34: rd = {0, 0, 0}  // glm::circularRand(lensRadius)
+    if (thin_lens) {                       // HRT_FLAG_THIN_LENS: that commented-out call, camera.h:34-35
+        u32x4 l = rng_draw(g_ctx, RNG_LENS, 0);
+        float rx, ry;
+        circular_rand(l.x, c->lens_radius, rx, ry);
+        offset = vec3(c->lens_u[0], c->lens_u[1], c->lens_u[2]) * rx + vec3(c->lens_v[0], c->lens_v[1], c->lens_v[2]) * ry;
+    }
     return ray(origin + offset, llc + s * hor + t * ver - origin - offset);
 }
 
@@ -892,7 +898,7 @@ int oracle_render_tile(oracle_world* h, const hrt_camera* cam, const hrt_params*
                     float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (W - 1);
                     float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (H - 1);
                     g_cnt.samples++;
-                    pixelColour += rayColour(getRay(cam, u, v), *h->w, h->fs, pr->max_depth, pr->t_min);
+                    pixelColour += rayColour(getRay(cam, u, v, (pr->flags & HRT_FLAG_THIN_LENS) != 0), *h->w, h->fs, pr->max_depth, pr->t_min);
                 }
                 pixelColour = pixelColour / static_cast<float>(pr->samples);
                 float* o = out + 3 * ((size_t)ry * tile.w + rx);
@@ -949,7 +955,7 @@ int oracle_trace_path(oracle_world* h, const hrt_camera* cam, const hrt_params* 
     u32x4 j = rng_draw(g_ctx, RNG_JITTER, 0);
     float u = ((float)x + linear_rand(j.x, 0.0f, 1.0f)) / (W - 1);
     float v = ((float)y + linear_rand(j.y, 0.0f, 1.0f)) / (H - 1);
-    ray r = getRay(cam, u, v);
+    ray r = getRay(cam, u, v, (pr->flags & HRT_FLAG_THIN_LENS) != 0);
     int n = 0;
     for (int i = 0; i < pr->max_depth && n < max_seg; ++i) {
         g_ctx.bounce = (uint32_t)i;

@@ -510,3 +510,23 @@ def test_full_size_bust_hit_records_and_small_film(built, assets_full, scenes_di
             assert st.rays == sr.rays and sr.mesh_hits > 5000, (q, tail, mega)
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (q, tail, mega)
     dev.close()
+
+
+def test_thin_lens_flag_on_every_render_path(built, assets, scenes_dir, monkeypatch):
+    """HRT_FLAG_THIN_LENS (camera.h:34's commented-out circularRand(lensRadius), hrt.h hrt_camera): pipeline, tail and megakernel
+    equal the oracle; the CPU twin (test_flat_vs_oracle_cpu.py) checks what the flag means."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    hs = api.HostScene(f"{scenes_dir}/bust_scene.yaml", assets)
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    W, H, spp = 56, 40, 5
+    cam = hs.camera(W, H)
+    cam.lens_radius = 0.12
+    ref, sr = world.render_tile(cam, api.default_params(W, H, spp, thin_lens=True, stats=True))
+    pin, _ = world.render_tile(cam, api.default_params(W, H, spp))
+    assert not np.array_equal(ref, pin)
+    for tail, mega in (("1", False), ("1000", False), ("1", True)):
+        monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+        img, st = dev.render_tile(cam, api.default_params(W, H, spp, thin_lens=True, stats=True, megakernel=mega))
+        assert st.rays == sr.rays and np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (tail, mega)
+    dev.close()
