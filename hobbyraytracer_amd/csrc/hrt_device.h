@@ -912,12 +912,12 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     vec3 lo = o, ld = d;
     const int n = pr.n_xforms;
     // The wrapper chain, outermost first; d_k = the direction wrapper k handed to its child.  Written as NESTED ifs on
-    // purpose: the flat form (`#pragma unroll for k: if (k < n) xf_apply(xf[k])`, four independent predicated blocks)
-    // is miscompiled by hipcc 7.2 for gfx950 inside k_wf_shade / k_wf_tail -- a per-lane chain of exactly three
-    // wrappers came back with a wrong rec.p (found by tests/scene_helpers.py random_world; the megakernel, which inlines
-    // the same source, was right; adding a printf made it right).  Nested ifs, a runtime loop and a noinline function
-    // were all correct; this form costs nothing (k_wf_shade 21.2 ms vs 21.5 ms on the headline frame).
-    // tests/test_gpu_scenes.py::test_wrapper_chains_of_every_length pins it.
+    // purpose: the flat form (`#pragma unroll for k: if (k < n) xf_apply(xf[k])`, four independent predicated blocks) is
+    // miscompiled by hipcc 7.2 for gfx950 inside k_wf_shade / k_wf_tail -- a per-lane chain of exactly three wrappers whose
+    // innermost one is a rotate_y came back with a wrong rec.p.  Root-caused in round 2 (tests/tools/repro_wrapper_chain.md):
+    // SimplifyCFG's sinking of common instructions plus the SLP vectorizer on the unrolled blocks; either pass off, -O1, or
+    // this nested shape (block k + 1 inside block k's condition) is right.  The flat shape is kept compilable behind
+    // -DHRT_XF_FLAT for the reproducer; tests/test_gpu_scenes.py::test_wrapper_chains_of_every_length pins the result.
     vec3 d0 = d, d1 = d, d2 = d, d3 = d;
     static_assert(HRT_MAX_XFORMS == 4, "world_rec spells the wrapper chain out");
 #ifdef HRT_XF_FLAT   // the shape that came out wrong (tests/tools/repro_wrapper_chain.md): kept compilable for the reproducer only

@@ -166,8 +166,8 @@ typedef struct hrt_flat_scene {
                               padded ITriangle boxes of triangle.cpp:133-151).  The reference rejects a
                               triangle hit whose leaf-level box fails AABB::hit (bvh.cpp:71), which matters
                               for the t < t_min self-hits of Q-2; the flattened BVH applies the same test to
-                              accepted candidates so results do not depend on ITS topology.  NULL = use each
-                              triangle's own padded box. */
+                              accepted candidates so results do not depend on ITS topology.  NULL = derived by the
+                              library from tri_pos and tri_ref_order (hrt_pack.h pack_ref_tree). */
     const uint32_t* tri_ref_order; /* per triangle: (node << 1) | side, where `node` numbers the lowest
                               BVHNodes of the reference's own tree for the mesh in depth-first order and
                               `side` is 0 for that node's `left` child, 1 for `right` (bvh.cpp:20-36).  Once
@@ -176,7 +176,14 @@ typedef struct hrt_flat_scene {
                               keeps the one in the FIRST node its walk meets — except that the `right`
                               triangle of that same node is still tested (no box in between, bvh.cpp:75) and
                               wins if it is not farther.  The flattened traversal reproduces exactly that.
-                              NULL = every triangle its own node. */
+                              The codes also DEFINE the reference's whole tree for the library: the reference sorts and
+                              splits at start + n / 2 (bvh.cpp:39-43), so a node is a contiguous range of the depth-first
+                              order and its box the union of the padded triangle boxes of the range; rays whose
+                              ITriangle::hit arithmetic has gone meaningless (quirk Q-4 with a vanishing direction
+                              component on the shear axis) are walked through THAT tree, node by node in its order
+                              (hrt_device.h ref_walk).  hrt_scene_create refuses codes that are not the depth-first
+                              code of such a tree.  NULL = the triangles in the given order (a tree whose sorts
+                              changed nothing). */
     uint64_t n_nodes;      const hrt_bvh_node* nodes;
     uint64_t n_texels_u8;  const uint8_t* texels_u8;
     uint64_t n_texels_f32; const float* texels_f32;
