@@ -246,10 +246,12 @@ __global__ void k_math_probe(int op, long long n, const float* __restrict__ in, 
 // Everything is driven by DEVICE-side counts: the host enqueues max_depth rounds with no synchronisation.
 struct WfBuf {
     // live-path state, two copies (read parity r & 1, written parity (r + 1) & 1), indexed by POSITION:
-    float4* S0[2];   // o.xyz, closest t
-    float4* S1[2];   // d.xyz, slot (bits)
-    float4* S2[2];   // attenuation, hit prim (bits)
-    int* S3[2];      // hit sub = triangle / box side
+    float4* S0[2];   // o.xyz, d.x
+    float4* S1[2];   // d.yz, attenuation.xy
+    float4* S2[2];   // the hit so far: closest t, prim (bits), sub = triangle / box side (bits) | slot (bits).  The traversal
+                     // kernel's result is ONE 12-byte store into this record (three scattered 4-byte stores into three records
+                     // cost 204 MB of HBM writes per launch for ~14 MB of results: profiles/r01_v4)
+    float* S3[2];    // attenuation.z
     // The running `result` of main.cpp:41 is NOT carried: Material::emitted is non-zero only for DiffuseLight
     // (material.h:67-70, 101-104), which never scatters (material.h:96-99), so result is still exactly 0 when a
     // path reaches its last segment and `0 + atten * x` is exact.
@@ -414,10 +416,15 @@ __device__ HRT_WAVE_FN void wf_enqueue(const WfBuf& w, int kind, const MeshRay& 
     }
 }
 __device__ inline void wf_store_state(const WfBuf& w, int par, unsigned pos, const PathState& ps, float closest, unsigned slot, int prim, int sub) {
-    w.S0[par][pos] = make_float4(ps.o.x, ps.o.y, ps.o.z, closest);
-    w.S1[par][pos] = make_float4(ps.d.x, ps.d.y, ps.d.z, __uint_as_float(slot));
-    w.S2[par][pos] = make_float4(ps.atten.x, ps.atten.y, ps.atten.z, __int_as_float(prim));
-    w.S3[par][pos] = sub;
+    w.S0[par][pos] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    w.S1[par][pos] = make_float4(ps.d.y, ps.d.z, ps.atten.x, ps.atten.y);
+    w.S2[par][pos] = make_float4(closest, __int_as_float(prim), __int_as_float(sub), __uint_as_float(slot));
+    w.S3[par][pos] = ps.atten.z;
+}
+// the hit-so-far part of a state record (what the stages between two shadings update)
+__device__ inline void wf_store_hit(const WfBuf& w, int par, unsigned pos, int prim, int sub, float t) {
+    float3 h; h.x = t; h.y = __int_as_float(prim); h.z = __int_as_float(sub);
+    *(float3*)&w.S2[par][pos] = h;
 }
 
 // A task's ref-walk rays are announced to the launch that will walk them (lane 0 of the wave that prepared them).
@@ -483,18 +490,14 @@ __device__ HRT_WAVE_FN unsigned wf_pre_task(const DScene& sc, const hrt_params& 
         MeshRay mr;
         float closest = 0.0f;
         if (j0 + lane < n) {
-            const float4 a = w.S0[par][pos], b = w.S1[par][pos];
-            const vec3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
-            closest = a.w;
-            int prim = __float_as_int(w.S2[par][pos].w), sub = w.S3[par][pos];
+            const float4 a = w.S0[par][pos], b = w.S1[par][pos], h = w.S2[par][pos];
+            const vec3 o(a.x, a.y, a.z), d(a.w, b.x, b.y);
+            closest = h.x;
+            int prim = __float_as_int(h.y), sub = __float_as_int(h.z);
             const int prim0 = prim;
-            const rng_ctx ctx = slot_ctx(pr, map, __float_as_uint(b.w), n_local, s0, round);
+            const rng_ctx ctx = slot_ctx(pr, map, __float_as_uint(h.w), n_local, s0, round);
             enq = wf_prepare<STATS>(sc, pr, p0, mesh_prim, mesh_prim, o, d, ctx, closest, prim, sub, mr, n_culled);
-            if (prim != prim0) {
-                ((float*)&w.S0[par][pos])[3] = closest;
-                ((float*)&w.S2[par][pos])[3] = __int_as_float(prim);
-                w.S3[par][pos] = sub;
-            }
+            if (prim != prim0) wf_store_hit(w, par, pos, prim, sub, closest);
         }
         wf_enqueue(w, enq, mr, closest, pos, lt, qpos, base + w.T - 1, rcount);
     }
@@ -550,11 +553,6 @@ __device__ inline RefMesh wf_ref_mesh(const DScene& sc, int mesh_prim) {
     m.nodes = sc.rnodes + 2ull * rm[0]; m.tris = sc.rtris + 3ull * rm[2]; m.node_count = rm[1];
     m.tbox = sc.tri_box + 2ull * mesh.tri_first; m.tri_count = mesh.tri_count;
     return m;
-}
-__device__ inline void wf_store_hit(const WfBuf& w, int par, unsigned pos, int mesh_prim, int tri, float t) {
-    ((float*)&w.S0[par][pos])[3] = t;
-    ((float*)&w.S2[par][pos])[3] = __int_as_float(mesh_prim);
-    w.S3[par][pos] = tri;
 }
 // One LANE walks the reference's tree for the ray of record q (ref_walk: node by node, verbatim) and stores a hit like wf_ext_run does.
 template <bool STATS>
@@ -811,11 +809,7 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
                 float t;
                 int tri = trav_result(ts, em.tpos, em.tbox, r, pr.t_min, t);
                 if (tri >= 0 && trav_tie_overflow(ts)) tri |= HRT_SUB_TIE_UNSETTLED;      // three-way near-tie: world_rec settles it
-                if (tri >= 0) {
-                    ((float*)&w.S0[par][pos])[3] = t;
-                    ((float*)&w.S2[par][pos])[3] = __int_as_float(mesh_prim);
-                    w.S3[par][pos] = tri;
-                }
+                if (tri >= 0) wf_store_hit(w, par, pos, mesh_prim, tri, t);
                 has = false;
             }
         }
@@ -893,8 +887,8 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
     for (unsigned j0 = 0; j0 < n; j0 += 64) {
         const unsigned pos = base + j0 + lane;
         float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-        int sub0 = -1;
-        if (j0 + lane < n) { a = w.S0[par][pos]; b = w.S1[par][pos]; c = w.S2[par][pos]; sub0 = w.S3[par][pos]; }
+        float az = 0.0f;
+        if (j0 + lane < n) { a = w.S0[par][pos]; b = w.S1[par][pos]; c = w.S2[par][pos]; az = w.S3[par][pos]; }
         bool alive = false;
         PathState ps;
         unsigned slot = 0;
@@ -903,11 +897,11 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
         WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = 0.0f;
         if (j0 + lane < n) {
             n_seg++;
-            ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(b.x, b.y, b.z);
-            ps.atten = vec3(c.x, c.y, c.z); ps.result = vec3(0.0f); ps.bounce = round;
-            slot = __float_as_uint(b.w);
-            float closest = a.w;
-            int prim = __float_as_int(c.w), sub = sub0;
+            ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(a.w, b.x, b.y);
+            ps.atten = vec3(b.z, b.w, az); ps.result = vec3(0.0f); ps.bounce = round;
+            slot = __float_as_uint(c.w);
+            float closest = c.x;
+            int prim = __float_as_int(c.y), sub = __float_as_int(c.z);
             ctx = slot_ctx(pr, map, slot, n_local, s0, round);
             prims_range_hit(sc, ws.rest, sc.n_prims, ps.o, ps.d, pr.t_min, pr.quirks, ctx, closest, prim, sub);
             wh.prim = prim; wh.sub = sub; wh.t = closest;
@@ -1387,7 +1381,7 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     char* p = (char*)base;
     auto take = [&](size_t bytes) { char* q = p; p += bytes; return q; };
     for (int k = 0; k < 2; ++k) {
-        w.buf.S0[k] = (float4*)take(f4); w.buf.S1[k] = (float4*)take(f4); w.buf.S2[k] = (float4*)take(f4); w.buf.S3[k] = (int*)take(i4);
+        w.buf.S0[k] = (float4*)take(f4); w.buf.S1[k] = (float4*)take(f4); w.buf.S2[k] = (float4*)take(f4); w.buf.S3[k] = (float*)take(i4);
     }
     w.buf.E0 = (float4*)take(f4); w.buf.E1 = (float4*)take(f4); w.buf.E2 = (float4*)take(f4); w.buf.E3 = (float4*)take(f4);
     w.buf.rad = (float4*)take(f4);
