@@ -61,6 +61,9 @@ inline uint64_t fastdiv_magic(uint32_t d) { return d <= 1 ? 0 : (uint64_t)(~0ull
 struct DeviceCounters {      // 64-bit accumulators in device memory
     unsigned long long rays, samples, box_tests, tri_tests, mesh_hits, env_lookups;
     unsigned long long trav_box_tests, trav_tri_tests;   // the share of box_tests / tri_tests counted inside k_wf_ext launches
+#ifdef HRT_EXT_PROFILE       // experiments (tests/tools/ext_profile_run.py): where the lanes of k_wf_ext are, phase by phase
+    unsigned long long prof[12];
+#endif
 };
 
 // Number of set bits of a wave mask BELOW the calling lane (v_mbcnt_lo/hi: no per-lane 64-bit mask to keep in registers).
@@ -757,6 +760,9 @@ __device__ HRT_WAVE_FN void wf_ref_consume(const RefMesh& rm, const hrt_params& 
         }
     }
 }
+#ifdef HRT_EXT_PROFILE
+__device__ DeviceCounters* g_prof_counters;
+#endif
 template <bool STATS, class NextRange>
 __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, int* stack, unsigned lane,
                                   unsigned long long lt, int leaf_num, DCounters& cnt, NextRange next_range) {
@@ -768,6 +774,9 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
     TravState ts;
     ts.cur = HRT_TRAV_DONE;
     unsigned pos = 0;
+#ifdef HRT_EXT_PROFILE
+    unsigned prof_[12] = {0};
+#endif
     for (;;) {
         const unsigned long long need = __ballot(!has);
         if (need && !wave_done) {
@@ -795,14 +804,30 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
             if (wave_done) break;
             continue;
         }
+#ifdef HRT_EXT_PROFILE
+        prof_[0] += 1;
+#endif
         for (;;) {
             const unsigned long long m_in = __ballot(has && trav_at_inner(ts));
             if (!m_in) break;
             const int n_leaf = __popcll(__ballot(has && trav_at_leaf(ts)));
             if (n_leaf * 64 >= leaf_num * (n_leaf + __popcll(m_in))) break;
+#ifdef HRT_EXT_PROFILE
+            prof_[1] += 1; prof_[2] += (unsigned)__popcll(m_in); prof_[8] += (unsigned)__popcll(__ballot(has));
+#endif
             if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt);
+#ifdef HRT_EXT_PROFILE
+            { const unsigned long long m2 = __ballot(has && trav_at_inner(ts)); if (m2) { prof_[1] += 1; prof_[2] += (unsigned)__popcll(m2); prof_[8] += (unsigned)__popcll(__ballot(has)); } }
+#endif
             if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt);
         }
+#ifdef HRT_EXT_PROFILE
+        {
+            const unsigned long long ml = __ballot(has && trav_at_leaf(ts));
+            if (ml) { prof_[3] += 1; prof_[4] += (unsigned)__popcll(ml); prof_[6] += (unsigned)__popcll(__ballot(has));
+                      prof_[5] += (unsigned)__popcll(__ballot(has && trav_at_leaf(ts) && (((unsigned)~ts.cur) & 7u) >= 1u)); }
+        }
+#endif
         if (has) {
             if (trav_at_leaf(ts)) trav_leaf<STATS>(em.tpos, em.tbox, r, ts, pr.t_min, pr.quirks, stack, cnt);
             if (ts.cur == HRT_TRAV_DONE) {
@@ -813,7 +838,13 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
                 has = false;
             }
         }
+#ifdef HRT_EXT_PROFILE
+        prof_[7] += (unsigned)__popcll(__ballot(!has));   // lanes without a ray at the end of an outer iteration
+#endif
     }
+#ifdef HRT_EXT_PROFILE
+    if (lane == 0) for (int k = 0; k < 12; ++k) if (prof_[k]) atomicAdd(&g_prof_counters->prof[k], (unsigned long long)prof_[k]);
+#endif
 }
 // One launch per round and mesh: persistent waves pull tasks (HRT_TASK_GROUPS) and their rays.
 // DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
@@ -826,6 +857,9 @@ __global__ __launch_bounds__(HRT_BLOCK) __attribute__((amdgpu_waves_per_eu(DEPTH
     const unsigned long long lt = (1ull << lane) - 1ull;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
     const unsigned wave = HRT_UNIFORM((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+#ifdef HRT_EXT_PROFILE
+    g_prof_counters = counters;
+#endif
     if (pr.quirks & HRT_Q4_SHEAR_FROM_ORIGIN)
         wf_ref_consume<STATS>(wf_ref_mesh(sc, mesh_prim), pr, mesh_prim, par, w, wave, (gridDim.x * blockDim.x) >> 6, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
     {
@@ -1805,6 +1839,15 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     DeviceCounters c;
     HIPCHK(hipMemcpy(&c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
+#ifdef HRT_EXT_PROFILE
+    if (c.prof[0]) {
+        const double in_steps = (double)c.prof[1], lf = (double)c.prof[3];
+        fprintf(stderr, "[ext profile] outer %llu | inner wave-steps %llu, lanes at inner %.1f %% of 64, lanes with a ray %.1f %% | leaf phases %llu, lanes at leaf %.1f %%, "
+                        "of them with 2 triangles %.1f %%, lanes with a ray %.1f %% | lanes without a ray at the end of an outer iteration %.1f %%\n",
+                c.prof[0], c.prof[1], 100.0 * c.prof[2] / (64.0 * in_steps), 100.0 * c.prof[8] / (64.0 * in_steps), c.prof[3], 100.0 * c.prof[4] / (64.0 * lf),
+                100.0 * c.prof[5] / (double)c.prof[4], 100.0 * c.prof[6] / (64.0 * lf), 100.0 * c.prof[7] / (64.0 * (double)c.prof[0]));
+    }
+#endif
     stats->rays = c.rays; stats->samples = c.samples; stats->box_tests = c.box_tests; stats->tri_tests = c.tri_tests;
     stats->mesh_hits = c.mesh_hits; stats->env_lookups = c.env_lookups;
     stats->traversal_box_tests = c.trav_box_tests; stats->traversal_tri_tests = c.trav_tri_tests;

@@ -1,3 +1,10 @@
+"""Where the 64 lanes of k_wf_ext are, phase by phase (GPU box, repo root).  Needs a library built with -DHRT_EXT_PROFILE:
+    hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DHRT_EXT_PROFILE -shared -o /tmp/libhrt_hip_prof.so \\
+          hobbyraytracer_amd/csrc/hrt_hip.hip -ldl
+    cp /tmp/libhrt_hip_prof.so hobbyraytracer_amd/lib/libhrt_hip.so && python3 tests/tools/ext_profile_run.py
+The library prints one "[ext profile]" line per hrt_scene_stats call (stderr).  Round 2, headline frame (640x640x100, 50 rounds):
+10.5 M outer iterations, 107.7 M inner wave-steps with 41 % of the 64 lanes AT an inner node while 87 % hold a ray (the rest wait at
+a postponed leaf or are done), 10.2 M leaf phases with 50 % of the lanes at a leaf (90 % of those leaves hold two triangles)."""
 import os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 from hobbyraytracer_amd import api
