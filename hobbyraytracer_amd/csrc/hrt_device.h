@@ -491,9 +491,10 @@ struct MeshRay {          // a ray in mesh space plus its per-ray constants
     vec3 o, d;
     TriRay tr;            // exact-arithmetic constants of the triangle test
     float idx, idy, idz;  // culling-only constants (free to differ from the reference: see header): 1/d,
-    float gx, gy, gz;     // and the slab test in the mesh's node-grid coordinates: t = q * g - o_ (q = 16-bit grid index)
+    float gx, gy, gz;     // and the slab test in the mesh's node-grid coordinates: t = q * g - o_ (q = 16-bit grid index);
+                          // bit 4 of each g says "negative": the rotation that brings the NEAR face of a node word down (node_test)
     float reach;          // mesh_ray_reach (only until mesh_ray_grid has run)
-    float oxl, oxh, oyl, oyh, ozl, ozh;   // (o - origin) / d per axis, shifted for the LOW / HIGH face of a box (see mesh_ray_grid)
+    float oxn, oxf, oyn, oyf, ozn, ozf;   // (o - origin) / d per axis, shifted for the NEAR / FAR face of a box (see mesh_ray_grid)
 };
 // Q-4: the shear axis comes from the ray ORIGIN (triangle.cpp:70), so the t of ITriangle::hit is only good to about
 // kappa * eps * M / |d[kZ]| (M = the size of the coordinates that cancel in v - o; kappa in the hundreds for a thin triangle
@@ -514,20 +515,37 @@ __device__ inline float mesh_ray_reach(vec3 o, float sZ, float4 origin, float4 s
 // box = origin + q * step  =>  t = (box - o) / d = q * (step / d) - (o - origin) / d
 // `reach`: every slab is also widened by the reach of a meaningless t under quirk Q-4 (mesh_ray_reach below; computed where the
 // ray is prepared and carried in its record: the traversal kernel's registers are counted).
+__device__ inline float grid_tag(float g) {
+    const uint32_t b = (uint32_t)__float_as_int(g);
+    return __int_as_float((int)((b & ~31u) | (g < 0 ? 16u : 0u)));
+}
+// a node word lo | hi << 16 turned so that the face the ray enters through is in the low half (g: a tagged MeshRay::gx..gz)
+__device__ inline uint32_t near_far(uint32_t w, float g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(w, w, (uint32_t)__float_as_int(g));
+#else
+    return ((uint32_t)__float_as_int(g) & 16u) ? (w >> 16) | (w << 16) : w;
+#endif
+}
 __device__ inline void mesh_ray_grid(MeshRay& r, float4 origin, float4 step, float reach) {
-    r.gx = r.idx * step.x; r.gy = r.idy * step.y; r.gz = r.idz * step.z;
+    const float gx = r.idx * step.x, gy = r.idy * step.y, gz = r.idz * step.z;
     const float ox = (r.o.x - origin.x) * r.idx, oy = (r.o.y - origin.y) * r.idy, oz = (r.o.z - origin.z) * r.idz;
     // t = q * g - o_ carries the rounding of both terms: up to ~1.2e-7 of their magnitudes, which is no longer small
     // against the boxes when the ray starts thousands of mesh extents away (a mesh seen from 1e5 units: 4 of 57 k hits
     // were culled, at 1e6 units 1863).  The reference's own slab test rounds just as badly but is not what culls here,
     // so every slab is widened by s = 4e-7 x (largest |q * g| + |o_|) at no cost in the loop: the face the ray ENTERS
-    // through gets o_ + s, the one it leaves through o_ - s, and which is which is the sign of g, known per ray.
-    float sx = 4e-7f * (fabsf(r.gx) * 65535.0f + fabsf(ox)), sy = 4e-7f * (fabsf(r.gy) * 65535.0f + fabsf(oy)),
-          sz = 4e-7f * (fabsf(r.gz) * 65535.0f + fabsf(oz));
+    // through gets o_ + s, the one it leaves through o_ - s.
+    // Which face that is, is the sign of g, known per ray: the low five bits of g are given up to say so (0 or 16, the
+    // amount node_test rotates a node's lo|hi word by, read by v_alignbit straight from g's register: no register and no
+    // instruction of the traversal loop spent on it).  That moves g by up to 31 ulp = 3.7e-6 of itself (t by that x 65535 |g|;
+    // 32 denormal steps x 65535 < 1e-37 when g is that small), which the widening covers as well.
+    float sx = 4.2e-6f * fabsf(gx) * 65535.0f + 4e-7f * fabsf(ox) + 1e-37f, sy = 4.2e-6f * fabsf(gy) * 65535.0f + 4e-7f * fabsf(oy) + 1e-37f,
+          sz = 4.2e-6f * fabsf(gz) * 65535.0f + 4e-7f * fabsf(oz) + 1e-37f;
     sx += reach; sy += reach; sz += reach;
-    r.oxl = r.gx < 0 ? ox - sx : ox + sx; r.oxh = r.gx < 0 ? ox + sx : ox - sx;
-    r.oyl = r.gy < 0 ? oy - sy : oy + sy; r.oyh = r.gy < 0 ? oy + sy : oy - sy;
-    r.ozl = r.gz < 0 ? oz - sz : oz + sz; r.ozh = r.gz < 0 ? oz + sz : oz - sz;
+    r.gx = grid_tag(gx); r.gy = grid_tag(gy); r.gz = grid_tag(gz);
+    r.oxn = ox + sx; r.oxf = ox - sx;
+    r.oyn = oy + sy; r.oyf = oy - sy;
+    r.ozn = oz + sz; r.ozf = oz - sz;
 }
 __device__ inline MeshRay mesh_ray_setup(vec3 o, vec3 d, uint32_t quirks, float4 origin, float4 step) {
     MeshRay r;
@@ -606,16 +624,19 @@ __device__ inline float trav_t_lo(float t_min, uint32_t quirks) { return (quirks
 // Slab test of BOTH child boxes of one 32-byte node against [t_lo, t_hi] (culling only).
 __device__ inline void node_test(const uint4& A, const uint4& B, const MeshRay& r, float t_lo, float t_hi,
                                  float& tn0, bool& h0, float& tn1, bool& h1) {
-    float a0 = fmaf((float)(A.x & 0xffffu), r.gx, -r.oxl), a1 = fmaf((float)(A.x >> 16), r.gx, -r.oxh);
-    float b0 = fmaf((float)(A.y & 0xffffu), r.gy, -r.oyl), b1 = fmaf((float)(A.y >> 16), r.gy, -r.oyh);
-    float c0 = fmaf((float)(A.z & 0xffffu), r.gz, -r.ozl), c1 = fmaf((float)(A.z >> 16), r.gz, -r.ozh);
-    tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), t_lo));
-    float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), t_hi));
-    float e0 = fmaf((float)(B.x & 0xffffu), r.gx, -r.oxl), e1 = fmaf((float)(B.x >> 16), r.gx, -r.oxh);
-    float f0 = fmaf((float)(B.y & 0xffffu), r.gy, -r.oyl), f1 = fmaf((float)(B.y >> 16), r.gy, -r.oyh);
-    float g0 = fmaf((float)(B.z & 0xffffu), r.gz, -r.ozl), g1 = fmaf((float)(B.z >> 16), r.gz, -r.ozh);
-    tn1 = fmaxf(fmaxf(fminf(e0, e1), fminf(f0, f1)), fmaxf(fminf(g0, g1), t_lo));
-    float tf1 = fminf(fminf(fmaxf(e0, e1), fmaxf(f0, f1)), fminf(fmaxf(g0, g1), t_hi));
+    // per axis: entry = near face, exit = far face (no min / max of the two: the rotation has sorted them)
+    const uint32_t ax = near_far(A.x, r.gx), ay = near_far(A.y, r.gy), az = near_far(A.z, r.gz);
+    float a0 = fmaf((float)(ax & 0xffffu), r.gx, -r.oxn), a1 = fmaf((float)(ax >> 16), r.gx, -r.oxf);
+    float b0 = fmaf((float)(ay & 0xffffu), r.gy, -r.oyn), b1 = fmaf((float)(ay >> 16), r.gy, -r.oyf);
+    float c0 = fmaf((float)(az & 0xffffu), r.gz, -r.ozn), c1 = fmaf((float)(az >> 16), r.gz, -r.ozf);
+    tn0 = fmaxf(fmaxf(fmaxf(a0, b0), c0), t_lo);
+    float tf0 = fminf(fminf(fminf(a1, b1), c1), t_hi);
+    const uint32_t bx = near_far(B.x, r.gx), by = near_far(B.y, r.gy), bz = near_far(B.z, r.gz);
+    float e0 = fmaf((float)(bx & 0xffffu), r.gx, -r.oxn), e1 = fmaf((float)(bx >> 16), r.gx, -r.oxf);
+    float f0 = fmaf((float)(by & 0xffffu), r.gy, -r.oyn), f1 = fmaf((float)(by >> 16), r.gy, -r.oyf);
+    float g0 = fmaf((float)(bz & 0xffffu), r.gz, -r.ozn), g1 = fmaf((float)(bz >> 16), r.gz, -r.ozf);
+    tn1 = fmaxf(fmaxf(fmaxf(e0, f0), g0), t_lo);
+    float tf1 = fminf(fminf(fminf(e1, f1), g1), t_hi);
     h0 = tn0 <= tf0;
     h1 = tn1 <= tf1;
 }

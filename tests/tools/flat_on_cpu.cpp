@@ -15,6 +15,7 @@
 struct float4 { float x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 
 #include "../../hobbyraytracer_amd/csrc/hrt_device.h"
 #include "../../hobbyraytracer_amd/csrc/hrt_pack.h"
