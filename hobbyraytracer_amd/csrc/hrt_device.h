@@ -36,6 +36,8 @@ struct DScene {
     const uint4* rmesh;      // per mesh: first node, node count, first triangle in rtris, 0
     float q4_route_a2;       // rays with (|d| / |d[kZ]|)^2 above this take ref_walk (q4_risky)
     int32_t ref_fold_all;    // tests: bvh_traverse (megakernel, test kernels) takes ref_fold instead of ref_walk where it is valid
+    int32_t stale_ff;        // some mesh stands in the world list without a wrapper and has a Dielectric material: its hits take
+                             // hitRecord::frontFace from the previous successful object of the walk (WorldHit, "stale frontFace")
     const uint8_t* texels_u8;
     const float* texels_f32;
     int32_t n_prims;
@@ -874,13 +876,25 @@ __device__ inline void tri_rec(const DScene& sc, const hrt_mesh& mesh, int tri, 
 }
 
 // ------------------------------------------------------------------ world->hit (hittableList.cpp:4-21 over scene.cpp:376-379)
-struct WorldHit { int prim; int sub; float t; };  // sub = triangle index (mesh) or box side
+// Stale frontFace (hittableList.cpp:6-16 with triangle.cpp:118-128, quirk Q-3): HittableList::hit hands every object the same
+// tempRec, and ITriangle::hit never writes frontFace -- so the hit of a mesh that stands in the list WITHOUT a wrapper (a wrapper's
+// setFaceNormal would write it, translate.cpp:16) carries the flag of the previous successful object of that walk which does write
+// it: any object but another such mesh.  Only Dielectric::scatter reads the flag (material.h:207), so this is tracked only in
+// scenes that have such a mesh with such a material (DScene::stale_ff): the winner's `sub` gets HRT_SUB_WRAPPERLESS, and
+// (s_prim, s_sub, s_t) name the hit whose flag it inherits, s_prim = -1 when there was none (the reference then reads an
+// uninitialised bool; defined `true` here and in the oracle).
+#define HRT_SUB_WRAPPERLESS 0x20000000
+// ... and the wavefront pipeline, which has resolved the source's flag in a stage of its own (k_wf_stale), says "it is false" here:
+#define HRT_SUB_STALE_BACK 0x10000000
+struct WorldHit { int prim; int sub; float t; int s_prim; int s_sub; float s_t; };  // sub = triangle index (mesh) or box side
+__device__ inline bool stale_ff_tracked(const DScene& sc, uint32_t quirks) { return sc.stale_ff && (quirks & HRT_Q3_TRI_NO_FACE); }
 
 template <bool STATS>
 __device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_min, float t_max, uint32_t quirks,
                                      const rng_ctx& ctx, int* stack, DCounters& cnt) {
-    WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = t_max;
+    WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = t_max; wh.s_prim = -1; wh.s_sub = -1; wh.s_t = 0.0f;
     float closest = t_max;
+    const bool track = stale_ff_tracked(sc, quirks);
     for (int i = 0; i < sc.n_prims; ++i) {
         const auto& pr = uniform_table(sc.prims)[i];
         vec3 lo = o, ld = d;
@@ -901,7 +915,13 @@ __device__ inline WorldHit world_hit(const DScene& sc, vec3 o, vec3 d, float t_m
         } else {
             hit = rect_hit(rect_axis(kind), pr.p, lo, ld, t_min, closest, t);
         }
-        if (hit) { closest = t; wh.prim = i; wh.sub = sub; wh.t = t; }
+        if (hit) {
+            if (track) {
+                if (kind == HRT_PRIM_MESH && pr.n_xforms == 0) sub |= HRT_SUB_WRAPPERLESS;      // inherits the flag: the source stays
+                else { wh.s_prim = i; wh.s_sub = sub; wh.s_t = t; }
+            }
+            closest = t; wh.prim = i; wh.sub = sub; wh.t = t;
+        }
     }
     return wh;
 }
@@ -928,7 +948,9 @@ __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o,
 }
 
 // Rebuilds the winner's hitRecord exactly as the reference's call chain does.
-__device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, float t_min_for_ties, DRec& rec) {
+// stale_back: the winner is a mesh hit marked HRT_SUB_WRAPPERLESS and the frontFace it inherits is `false`.
+__device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, float t_min_for_ties, DRec& rec,
+                                 bool stale_back = false) {
     const hrt_prim& pr = sc.lprims[wh.prim];
     vec3 lo = o, ld = d;
     const int n = pr.n_xforms;
@@ -968,7 +990,7 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     rec.frontFace = true;
     const int kind = pr.kind;
     if (kind == HRT_PRIM_MESH) {
-        int tri = wh.sub;
+        int tri = wh.sub & ~(HRT_SUB_WRAPPERLESS | HRT_SUB_STALE_BACK);
         if (tri & HRT_SUB_TIE_UNSETTLED) {
             // three or more hits within an ulp or two of each other: the reference's own walk decides (from a t_max just beyond
             // them: whatever lay clearly nearer would have won already)
@@ -980,6 +1002,7 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
             tri = exact >= 0 ? exact : (tri & ~HRT_SUB_TIE_UNSETTLED);
         }
         tri_rec(sc, sc.lmeshes[pr.mesh], tri, lo, ld, quirks, rec);
+        if (stale_back) rec.frontFace = false;      // (only ever set for a wrapper-less mesh under Q-3: nothing below rewrites it)
     }
     else if (kind == HRT_PRIM_SPHERE) sphere_rec(pr.p, lo, ld, wh.t, rec);
     else if (kind == HRT_PRIM_BOX) box_rec(pr.p, lo, ld, wh.t, wh.sub, rec);
@@ -1004,6 +1027,24 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
             xf_unapply(pr.xf[1], rec, d1);
         }
         xf_unapply(pr.xf[0], rec, d0);
+    }
+}
+
+// The hitRecord main.cpp:46 gets back for the winner `wh` (wh.prim >= 0).  A wrapper-less mesh hit with a source for its
+// frontFace: the source's record first, for that one flag (ONE world_rec body run twice by those lanes, not two bodies: the
+// registers of k_wf_shade are counted).
+__device__ inline void hit_record(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, float t_min_for_ties, DRec& rec) {
+    const bool wrapperless = sc.lprims[wh.prim].kind == HRT_PRIM_MESH && (wh.sub & HRT_SUB_WRAPPERLESS);
+    bool stale_back = wrapperless && (wh.sub & HRT_SUB_STALE_BACK);
+    const bool inherits = wrapperless && !stale_back && wh.s_prim >= 0;
+    WorldHit cur = wh;
+    if (inherits) { cur.prim = wh.s_prim; cur.sub = wh.s_sub; cur.t = wh.s_t; }
+#if defined(__HIPCC__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int pass = inherits ? 0 : 1; pass < 2; ++pass) {
+        world_rec(sc, cur, o, d, quirks, t_min_for_ties, rec, stale_back);
+        if (pass == 0) { stale_back = !rec.frontFace; cur = wh; }
     }
 }
 
@@ -1165,7 +1206,7 @@ __device__ inline bool path_shade(const DScene& sc, const hrt_params& pr, const 
     }
     if (STATS && sc.lprims[wh.prim].kind == HRT_PRIM_MESH) pc.mesh_hits++;
     DRec rec;
-    world_rec(sc, wh, ps.o, ps.d, pr.quirks, pr.t_min, rec);
+    hit_record(sc, wh, ps.o, ps.d, pr.quirks, pr.t_min, rec);
     vec3 emitted, attenuation, so, sd;
     const bool b = material_scatter(sc, rec, ps.d, ctx, emitted, attenuation, so, sd);
     ps.result += ps.atten * emitted;

@@ -183,15 +183,16 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_closest_hit(DScene sc, hrt_params
     const vec3 d(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
     rng_ctx ctx; ctx.seed_lo = pr.seed_lo; ctx.seed_hi = pr.seed_hi; ctx.pixel = pixel0 + (uint32_t)i; ctx.sample = 0; ctx.bounce = 0;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
+    sc.stale_ff = 1;      // the hit RECORD always carries the inherited frontFace (renders track it only where a material reads it)
     const WorldHit wh = world_hit<false>(sc, o, d, t_min, t_max, pr.quirks, ctx, stack, cnt);
     hrt_hit h;
     memset(&h, 0, sizeof(h));
     h.prim = wh.prim; h.tri = -1;
     if (wh.prim >= 0) {
         DRec rec;
-        world_rec(sc, wh, o, d, pr.quirks, t_min, rec);
+        hit_record(sc, wh, o, d, pr.quirks, t_min, rec);
         h.t = rec.t;
-        h.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? wh.sub : -1;
+        h.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? (wh.sub & ~(HRT_SUB_WRAPPERLESS | HRT_SUB_STALE_BACK)) : -1;
         h.front_face = rec.frontFace ? 1 : 0;
         h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
         h.normal[0] = rec.normal.x; h.normal[1] = rec.normal.y; h.normal[2] = rec.normal.z;
@@ -255,6 +256,7 @@ struct WfBuf {
                      // kernel's result is ONE 12-byte store into this record (three scattered 4-byte stores into three records
                      // cost 204 MB of HBM writes per launch for ~14 MB of results: profiles/r01_v4)
     float* S3[2];    // attenuation.z
+    float4* S4;      // scenes that track the stale frontFace only (wf_store_hit): t, prim, sub of the hit a wrapper-less mesh hit inherits it from
     // The running `result` of main.cpp:41 is NOT carried: Material::emitted is non-zero only for DiffuseLight
     // (material.h:67-70, 101-104), which never scatters (material.h:96-99), so result is still exactly 0 when a
     // path reaches its last segment and `0 + atten * x` is exact.
@@ -425,7 +427,18 @@ __device__ inline void wf_store_state(const WfBuf& w, int par, unsigned pos, con
     w.S3[par][pos] = ps.atten.z;
 }
 // the hit-so-far part of a state record (what the stages between two shadings update)
-__device__ inline void wf_store_hit(const WfBuf& w, int par, unsigned pos, int prim, int sub, float t) {
+// stale (wave-uniform): this is the hit of a mesh that stands in the world list without a wrapper, in a scene that tracks the
+// stale frontFace (hrt_device.h WorldHit).  What the record holds so far IS the previous success of the list walk
+// (hittableList.cpp:12-19: the stages run in list order): it is put aside in S4 as the source of the flag this hit inherits --
+// unless it is such a mesh hit itself, which inherited its flag from the source already there.
+__device__ inline void wf_store_hit(const WfBuf& w, int par, unsigned pos, int prim, int sub, float t, bool stale = false) {
+    if (stale) {
+        const float4 old = w.S2[par][pos];
+        const int os = __float_as_int(old.z);
+        if (__float_as_int(old.y) < 0) w.S4[pos] = make_float4(0.0f, __int_as_float(-1), __int_as_float(-1), 0.0f);
+        else if (!(os >= 0 && (os & HRT_SUB_WRAPPERLESS))) w.S4[pos] = old;
+        sub |= HRT_SUB_WRAPPERLESS;
+    }
     float3 h; h.x = t; h.y = __int_as_float(prim); h.z = __int_as_float(sub);
     *(float3*)&w.S2[par][pos] = h;
 }
@@ -525,6 +538,34 @@ __global__ __launch_bounds__(256) void k_wf_pre(DScene sc, hrt_params pr, Render
     }
 }
 
+// Scenes that track the stale frontFace (hrt_device.h WorldHit), after the round's last traversal: a path whose hit so far is
+// that of a wrapper-less mesh and has a source for its flag (S4, wf_store_hit) gets the source's hitRecord built for that one
+// bit; "false" is noted in the hit's sub-index (HRT_SUB_STALE_BACK), which is all k_wf_shade needs.  A stage of its own: a
+// second hitRecord body inside k_wf_shade costs every scene 9 VGPRs and a spill.
+__global__ __launch_bounds__(256) void k_wf_stale(DScene sc, hrt_params pr, int par, WfBuf w) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
+    stage_tables(sc, s_tables);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    HRT_FOR_MY_TASKS(task, w, wave, lane) {
+        const unsigned base = task * w.T, n = HRT_UNIFORM(w.live[task]);
+        for (unsigned j0 = 0; j0 < n; j0 += 64) {
+            const unsigned pos = base + j0 + lane;
+            if (j0 + lane >= n) continue;
+            const float4 h = w.S2[par][pos];
+            const int prim = __float_as_int(h.y), sub = __float_as_int(h.z);
+            if (prim < 0 || sub < 0 || !(sub & HRT_SUB_WRAPPERLESS) || sc.lprims[prim].kind != HRT_PRIM_MESH) continue;
+            const float4 src = w.S4[pos];
+            WorldHit wh; wh.t = src.x; wh.prim = __float_as_int(src.y); wh.sub = __float_as_int(src.z); wh.s_prim = -1; wh.s_sub = -1; wh.s_t = 0.0f;
+            if (wh.prim < 0) continue;
+            const float4 a = w.S0[par][pos], b = w.S1[par][pos];
+            DRec rec;
+            world_rec(sc, wh, vec3(a.x, a.y, a.z), vec3(a.w, b.x, b.y), pr.quirks, pr.t_min, rec);
+            if (!rec.frontFace) w.S2[par][pos].z = __int_as_float(sub | HRT_SUB_STALE_BACK);
+        }
+    }
+}
+
 // BVH traversal of queued rays of one mesh prim by one wave.  `next_range(first, end)` hands the wave its next run of
 // ray records (a task's queue) or returns false; finished lanes pull the next ray of the run (ballot + prefix count).
 // While-while with postponed leaves: inner nodes are walked (two steps per wave vote: the ballots, counts, compare and
@@ -535,8 +576,12 @@ struct ExtMesh {                 // wave-uniform per-mesh constants of the trave
     const uint4* nodes; const float4* tpos; const float4* tbox;
     float4 grid_o, grid_s;
     uint32_t node_count;
+    bool stale;                  // see wf_store_hit
 };
-__device__ inline ExtMesh wf_ext_mesh(const DScene& sc, int mesh_prim) {
+__device__ inline bool wf_mesh_stale(const DScene& sc, int mesh_prim, uint32_t quirks) {
+    return stale_ff_tracked(sc, quirks) && uniform_table(sc.prims)[mesh_prim].n_xforms == 0;
+}
+__device__ inline ExtMesh wf_ext_mesh(const DScene& sc, int mesh_prim, uint32_t quirks) {
     ExtMesh m;
     const auto& mp = uniform_table(sc.prims)[mesh_prim];
     const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
@@ -545,16 +590,18 @@ __device__ inline ExtMesh wf_ext_mesh(const DScene& sc, int mesh_prim) {
     m.tbox = sc.tri_box + 2ull * mesh.tri_first;
     mesh_grid(sc, mp.mesh, m.grid_o, m.grid_s);
     m.node_count = mesh.node_count;
+    m.stale = wf_mesh_stale(sc, mesh_prim, quirks);
     return m;
 }
-struct RefMesh { const uint4* nodes; const float4* tris; const float4* tbox; uint32_t node_count, tri_count; };   // the same for the reference-tree walks
-__device__ inline RefMesh wf_ref_mesh(const DScene& sc, int mesh_prim) {
+struct RefMesh { const uint4* nodes; const float4* tris; const float4* tbox; uint32_t node_count, tri_count; bool stale; };   // the same for the reference-tree walks
+__device__ inline RefMesh wf_ref_mesh(const DScene& sc, int mesh_prim, uint32_t quirks) {
     RefMesh m;
     const auto& mp = uniform_table(sc.prims)[mesh_prim];
     const auto& mesh = uniform_table(sc.meshes)[mp.mesh];
     const HRT_CONST_AS uint32_t* rm = uniform_table((const uint32_t*)sc.rmesh) + 4 * mp.mesh;
     m.nodes = sc.rnodes + 2ull * rm[0]; m.tris = sc.rtris + 3ull * rm[2]; m.node_count = rm[1];
     m.tbox = sc.tri_box + 2ull * mesh.tri_first; m.tri_count = mesh.tri_count;
+    m.stale = wf_mesh_stale(sc, mesh_prim, quirks);
     return m;
 }
 // One LANE walks the reference's tree for the ray of record q (ref_walk: node by node, verbatim) and stores a hit like wf_ext_run does.
@@ -566,7 +613,7 @@ __device__ HRT_WAVE_FN void wf_ref_one(const RefMesh& rm, const hrt_params& pr, 
     tr.o = o; tr.sX = e2.x; tr.sY = e2.y; tr.sZ = e2.z; tr.kZ = __float_as_int(e2.w);
     float t;
     const int tri = ref_walk<STATS>(rm.nodes, rm.tris, rm.node_count, o, d, tr, pr.t_min, e0.w, pr.quirks, t, cnt);
-    if (tri >= 0) wf_store_hit(w, par, __float_as_uint(e1.w), mesh_prim, tri, t);
+    if (tri >= 0) wf_store_hit(w, par, __float_as_uint(e1.w), mesh_prim, tri, t, rm.stale);
 }
 // One WAVE does the same for up to HRT_BFS_RAYS rays at once, breadth first.  A lane's walk is a chain of ~250 dependent
 // node fetches, ~1 us each once the shading kernels' streams have swept the L2: longer than a late round's whole traversal
@@ -713,7 +760,7 @@ __device__ HRT_WAVE_FN void wf_ref_bfs(const RefMesh& rm, const hrt_params& pr, 
         t_max = t;
         best = (int)ti;
     }
-    if (best >= 0) wf_store_hit(w, par, __float_as_uint(e1.w), mesh_prim, best, t_max);
+    if (best >= 0) wf_store_hit(w, par, __float_as_uint(e1.w), mesh_prim, best, t_max, rm.stale);
 }
 // The ref-walk rays of ONE task (k_wf_tail: by the wave that owns the task), HRT_BFS_RAYS at a time.
 template <bool STATS>
@@ -834,7 +881,7 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
                 float t;
                 int tri = trav_result(ts, em.tpos, em.tbox, r, pr.t_min, t);
                 if (tri >= 0 && trav_tie_overflow(ts)) tri |= HRT_SUB_TIE_UNSETTLED;      // three-way near-tie: world_rec settles it
-                if (tri >= 0) wf_store_hit(w, par, pos, mesh_prim, tri, t);
+                if (tri >= 0) wf_store_hit(w, par, pos, mesh_prim, tri, t, em.stale);
                 has = false;
             }
         }
@@ -861,9 +908,9 @@ __global__ __launch_bounds__(HRT_BLOCK) __attribute__((amdgpu_waves_per_eu(DEPTH
     g_prof_counters = counters;
 #endif
     if (pr.quirks & HRT_Q4_SHEAR_FROM_ORIGIN)
-        wf_ref_consume<STATS>(wf_ref_mesh(sc, mesh_prim), pr, mesh_prim, par, w, wave, (gridDim.x * blockDim.x) >> 6, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
+        wf_ref_consume<STATS>(wf_ref_mesh(sc, mesh_prim, pr.quirks), pr, mesh_prim, par, w, wave, (gridDim.x * blockDim.x) >> 6, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
     {
-        const ExtMesh em = wf_ext_mesh(sc, mesh_prim);
+        const ExtMesh em = wf_ext_mesh(sc, mesh_prim, pr.quirks);
         TaskPuller puller = HRT_TASK_PULLER(wave, w.n_groups);
         wf_ext_run<STATS>(em, pr, mesh_prim, par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
             unsigned t;
@@ -928,7 +975,7 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
         unsigned slot = 0;
         rng_ctx ctx; ctx.seed_lo = 0; ctx.seed_hi = 0; ctx.pixel = 0; ctx.sample = 0; ctx.bounce = 0;
         bool missed = false;
-        WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = 0.0f;
+        WorldHit wh; wh.prim = -1; wh.sub = -1; wh.t = 0.0f; wh.s_prim = -1; wh.s_sub = -1; wh.s_t = 0.0f;
         if (j0 + lane < n) {
             n_seg++;
             ps.o = vec3(a.x, a.y, a.z); ps.d = vec3(a.w, b.x, b.y);
@@ -1059,11 +1106,11 @@ __global__ __launch_bounds__(256, 2) void k_wf_tail(DScene sc, hrt_params pr, Re
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 }
                 if (rn) {
-                    wf_ref_task<STATS>(wf_ref_mesh(sc, tm.prim[m]), pr, tm.prim[m], par, w, task, rn, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
+                    wf_ref_task<STATS>(wf_ref_mesh(sc, tm.prim[m], pr.quirks), pr, tm.prim[m], par, w, task, rn, s_stack + (threadIdx.x & ~63u), DEPTH * 64u, lane, cnt);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 }
                 if (qn) {
-                    const ExtMesh em = wf_ext_mesh(sc, tm.prim[m]);
+                    const ExtMesh em = wf_ext_mesh(sc, tm.prim[m], pr.quirks);
                     bool given = false;
                     const unsigned first0 = task * w.T, end0 = first0 + qn;
                     wf_ext_run<STATS>(em, pr, tm.prim[m], par, w, s_stack + threadIdx.x, lane, lt, leaf_num, cnt, [&](unsigned& first, unsigned& end) {
@@ -1392,7 +1439,8 @@ size_t wf_max_slots(const hrt_scene* sc) {
 }
 
 // "next task" counters: one block of 256 words per kernel launch of a batch (gen + per round: ext and pre per mesh, shade)
-size_t wf_counter_words(int depth, int n_mesh) { return (size_t)256 * (2 + (size_t)depth * (2 * (size_t)std::max(1, n_mesh) + 1)); }
+// (+ k_wf_stale in the scenes that have it)
+size_t wf_counter_words(int depth, int n_mesh) { return (size_t)256 * (2 + (size_t)depth * (2 * (size_t)std::max(1, n_mesh) + 2)); }
 // ... and of 512 words per traversal launch for its ref-walk lists (WfBuf::ref_prod / ref_cons), + one block nobody reads
 size_t wf_ref_counter_words(int depth, int n_mesh) { return (size_t)512 * ((size_t)depth * (size_t)std::max(1, n_mesh) + 1); }
 
@@ -1407,7 +1455,7 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     const size_t i4 = al((slots + 4096) * sizeof(int));
     const size_t ctr_words = wf_counter_words(depth, n_mesh) + wf_ref_counter_words(depth, n_mesh);
     const size_t ref_cap = max_tasks / HRT_REF_GROUPS + 1;
-    const size_t total = 11 * f4 + 2 * i4 + 3 * al(max_tasks * sizeof(unsigned)) + al(ctr_words * sizeof(unsigned)) + al(ref_cap * HRT_REF_GROUPS * sizeof(uint2)) +
+    const size_t total = (sc->ds.stale_ff ? 12 : 11) * f4 + 2 * i4 + 3 * al(max_tasks * sizeof(unsigned)) + al(ctr_words * sizeof(unsigned)) + al(ref_cap * HRT_REF_GROUPS * sizeof(uint2)) +
                          al((size_t)sc->n_cus * 32 * sizeof(unsigned long long));                                      // 184 B per slot
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, total);
@@ -1419,6 +1467,7 @@ hrt_status wf_reserve(hrt_scene* sc, size_t slots, int depth) {
     }
     w.buf.E0 = (float4*)take(f4); w.buf.E1 = (float4*)take(f4); w.buf.E2 = (float4*)take(f4); w.buf.E3 = (float4*)take(f4);
     w.buf.rad = (float4*)take(f4);
+    w.buf.S4 = sc->ds.stale_ff ? (float4*)take(f4) : nullptr;
     w.buf.live = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.qn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
     w.buf.rn = (unsigned*)take(al(max_tasks * sizeof(unsigned)));
@@ -1469,6 +1518,8 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     int tail_round = batch_slots <= ((size_t)512 << 10) ? 1 : (batch_slots <= ((size_t)6 << 20) ? 20 : D);
     if (const char* e = getenv("HRT_WF_TAIL_ROUND")) tail_round = std::max(1, atoi(e));
     if (n_mesh > HRT_TAIL_MAX_MESHES) tail_round = D;
+    const bool stale_ff = sc->ds.stale_ff && (pr->quirks & HRT_Q3_TRI_NO_FACE);
+    if (stale_ff) tail_round = D;        // k_wf_tail has no stage for the stale frontFace (k_wf_stale): round by round
     tail_round = std::min(tail_round, D);
     int leaf_num = 48;                                   // k_wf_ext: start the leaf phase when >= 48/64 of the busy lanes wait at a leaf
     if (const char* e = getenv("HRT_EXT_LEAF_NUM")) leaf_num = atoi(e);
@@ -1533,6 +1584,10 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
                 else { if (variant == 20) HRT_LAUNCH_EXT(false, 20); else if (variant == 24) HRT_LAUNCH_EXT(false, 24); else HRT_LAUNCH_EXT(false, 32); }
 #undef HRT_LAUNCH_EXT
                 if (timing) { HIPCHK(hipEventRecord(eb, stream)); sc->pending_trav.push_back({ea, eb}); }
+            }
+            if (stale_ff) {
+                next_counters((unsigned)task_blocks * 4u);
+                hipLaunchKernelGGL(k_wf_stale, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, par, w);
             }
             next_counters((unsigned)task_blocks * 4u);
             w.ref_prod = ref_block(r + 1, 0); w.ref_cons = ref_block(D, 0);
@@ -1724,6 +1779,7 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
         if (const char* e = getenv("HRT_Q4_ROUTE_A")) { const float v = (float)atof(e); if (v > 0.0f) a = v; }
         sc->ds.q4_route_a2 = a * a;
         sc->ds.ref_fold_all = getenv("HRT_REF_FOLD_ALL") ? 1 : 0;   // tests: the megakernel / test kernels fold instead of walking
+        sc->ds.stale_ff = scene_has_stale_front_face(f);
     }
     sc->ds.texels_u8 = d_u8; sc->ds.texels_f32 = d_f32;
     sc->ds.n_prims = (int32_t)f->n_prims;

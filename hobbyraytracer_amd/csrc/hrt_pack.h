@@ -218,4 +218,13 @@ inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, s
     }
 }
 
+// DScene::stale_ff: is there a mesh that stands in the world list without a wrapper and has a Dielectric material?
+inline int scene_has_stale_front_face(const hrt_flat_scene* f) {
+    for (uint32_t i = 0; i < f->n_prims; ++i) {
+        const hrt_prim& p = f->prims[i];
+        if (p.kind == HRT_PRIM_MESH && p.n_xforms == 0 && p.material >= 0 && (uint32_t)p.material < f->n_materials && f->materials[p.material].kind == HRT_MAT_DIELECTRIC) return 1;
+    }
+    return 0;
+}
+
 }  // namespace hrt

@@ -91,8 +91,9 @@ struct hitRecord {
     const Material* matPtr = nullptr;
     float t = 0.0f;
     float u = 0.0f, v = 0.0f;
-    // The reference leaves this uninitialised (main.cpp:44, hittableList.cpp:6)
-    // and ITriangle::hit never sets it (Q-3).  Defined here as `true`.
+    // The reference leaves this uninitialised (main.cpp:44, hittableList.cpp:6) and ITriangle::hit never sets it (Q-3): a mesh
+    // hit carries the flag of the previous successful object of the list walk, and the initial value -- indeterminate in the
+    // reference, defined `true` here -- when there was none.
     bool frontFace = true;
     int tri = -1;  // bookkeeping for the parity tests, not in the reference
     void setFaceNormal(const ray& r, vec3 outward_normal) {
@@ -486,8 +487,10 @@ struct ITriangle : Hittable {
         rec.u = uv.x;
         rec.v = uv.y;
         rec.tri = index;
-        if (g_quirks & HRT_Q3_TRI_NO_FACE) rec.frontFace = true;  // defined value for the reference's unset flag
-        else rec.setFaceNormal(r, normal);                         // Q-3 fixed
+        // Q-3: triangle.cpp:118-128 never write rec.frontFace.  `rec` is HittableList::hit's tempRec (hittableList.cpp:6-16, handed
+        // down through Mesh::hit and BVHNode::hit), shared by all objects of the walk: the flag keeps what the previous successful
+        // object wrote (a wrapper around the mesh overwrites it afterwards, translate.cpp:16), or its initial value.
+        if (!(g_quirks & HRT_Q3_TRI_NO_FACE)) rec.setFaceNormal(r, normal);   // Q-3 fixed
         return true;
     }
     bool boundingBox(AABB& out) override {  // triangle.cpp:133-151

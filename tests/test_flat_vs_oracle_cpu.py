@@ -477,3 +477,40 @@ def test_thin_lens_flag_matches_the_oracle_and_is_off_by_default(built, assets, 
     cam.lens_radius = 0.0
     zero, _ = FlatCpu(hs.flat_ptr).render_tile(cam, api.default_params(W, H, spp, thin_lens=True))
     assert np.array_equal(zero.view(np.uint32), pin.view(np.uint32))
+
+
+@pytest.mark.parametrize("enclosed", [True, False])
+def test_wrapperless_glass_mesh_inherits_the_front_face_of_the_previous_object(built, tmp_path, tools, enclosed):
+    """tests/scene_helpers.py stale_front_face_scene: hittableList.cpp:6-16 share one tempRec between all objects of a walk and
+    triangle.cpp:118-128 never write frontFace, so the hit of a mesh without a wrapper keeps the flag of the previous
+    successful object (hrt_device.h WorldHit).  Hit records and films as the oracle's, which restates the shared tempRec
+    literally; with the enclosing sphere every such hit inherits `false`."""
+    orc, FlatCpu = tools
+    from hobbyraytracer_amd import api
+    from tests.scene_helpers import stale_front_face_scene, films_equal
+    hs = api.HostScene(stale_front_face_scene(tmp_path, enclosed), str(tmp_path))
+    world, flat = orc.World(hs.flat_ptr), FlatCpu(hs.flat_ptr)
+    r = np.random.default_rng(5)
+    m = 20000
+    o = np.tile(np.array([[0.5, 1.5, 8.0]], np.float32), (m, 1))
+    d = (np.stack([r.uniform(-0.35, 0.25, m), r.uniform(-0.4, 0.1, m), np.full(m, -1.0)], 1)).astype(np.float32)
+    o[m // 2:] = np.array([0.3, 0.5, -2.5], np.float32); d[m // 2:, 2] = 1.0      # and from behind: the rectangles seen from their backs
+    first_mesh = 4 if enclosed else 3
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(8, 8, 1, quirks=q)
+        g, c = flat.closest_hit(p, o, d), world.closest_hit(p, o, d)
+        for k in ("prim", "tri", "front_face"):
+            assert np.array_equal(g[k], c[k]), (k, q)
+        assert np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32)) and np.array_equal(g["normal"].view(np.uint32), c["normal"].view(np.uint32))
+        bare = (c["prim"] == first_mesh) | (c["prim"] == first_mesh + 1)
+        assert bare.sum() > 2000
+        back = int((c["front_face"][bare] == 0).sum())
+        if q == api.QUIRKS_REFERENCE:      # the flag is inherited, not computed: from the sphere around everything, met from inside,
+            assert back > 5000 if enclosed else back == 0      # unless a wall seen from its front was met after it; else all `true`
+        else:
+            assert 0 < back < 500                              # Q-3 fixed: the few triangles really seen from behind
+        pr = api.default_params(48, 48, 4, quirks=q, stats=True)
+        a, sa = flat.render_tile(hs.camera(48, 48), pr)
+        b, sb = world.render_tile(hs.camera(48, 48), pr)
+        assert (sa.rays, sa.mesh_hits) == (sb.rays, sb.mesh_hits) and sb.mesh_hits > 5000
+        assert films_equal(a, b)

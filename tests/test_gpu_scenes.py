@@ -530,3 +530,37 @@ def test_thin_lens_flag_on_every_render_path(built, assets, scenes_dir, monkeypa
         img, st = dev.render_tile(cam, api.default_params(W, H, spp, thin_lens=True, stats=True, megakernel=mega))
         assert st.rays == sr.rays and np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (tail, mega)
     dev.close()
+
+
+@pytest.mark.parametrize("enclosed", [True, False])
+def test_wrapperless_glass_mesh_inherits_the_front_face_of_the_previous_object(built, tmp_path, monkeypatch, enclosed):
+    """The GPU twin of the CPU test of the same name (tests/scene_helpers.py stale_front_face_scene): the stale
+    hitRecord::frontFace of a mesh without a wrapper, on the wavefront pipeline (k_wf_ext puts the previous success aside,
+    k_wf_stale resolves its flag; one batch and several), the megakernel and the closest-hit kernel."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    from tests.scene_helpers import stale_front_face_scene, films_equal
+    hs = api.HostScene(stale_front_face_scene(tmp_path, enclosed), str(tmp_path))
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    W = H = 48
+    cam = hs.camera(W, H)
+    r = np.random.default_rng(5)
+    m = 20000
+    o = np.tile(np.array([[0.5, 1.5, 8.0]], np.float32), (m, 1))
+    d = (np.stack([r.uniform(-0.35, 0.25, m), r.uniform(-0.4, 0.1, m), np.full(m, -1.0)], 1)).astype(np.float32)
+    o[m // 2:] = np.array([0.3, 0.5, -2.5], np.float32); d[m // 2:, 2] = 1.0
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        p = api.default_params(8, 8, 1, quirks=q)
+        g, c = dev.closest_hit(p, o, d), world.closest_hit(p, o, d)
+        for k in ("prim", "tri", "front_face"):
+            assert np.array_equal(g[k], c[k]), (k, q)
+        assert np.array_equal(g["normal"].view(np.uint32), c["normal"].view(np.uint32))
+        ref, sr = world.render_tile(cam, api.default_params(W, H, 4, quirks=q, stats=True))
+        for tail, mega, slots in (("1", False, None), ("1000", False, None), ("1000", False, str(W * H)), ("1", True, None)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            if slots: monkeypatch.setenv("HRT_WF_MAX_SLOTS", slots)
+            img, st = dev.render_tile(cam, api.default_params(W, H, 4, quirks=q, stats=True, megakernel=mega))
+            if slots: monkeypatch.delenv("HRT_WF_MAX_SLOTS")
+            assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits), (q, tail, mega, slots)
+            assert films_equal(img, ref), (q, tail, mega, slots)
+    dev.close()

@@ -39,6 +39,7 @@ CpuScene* make(const hrt_flat_scene* f) {
         if (const char* e = getenv("HRT_Q4_ROUTE_A")) a = (float)atof(e);
         s->ds.q4_route_a2 = a * a;
         s->ds.ref_fold_all = getenv("HRT_REF_FOLD_ALL") ? 1 : 0;
+        s->ds.stale_ff = scene_has_stale_front_face(f);
     }
     s->ds.prims = f->prims; s->ds.mats = f->materials; s->ds.texs = f->textures; s->ds.meshes = f->meshes;
     pack_nodes(f, s->qnodes, s->grids);
@@ -63,7 +64,8 @@ const float* flatcpu_grids(void* h, uint64_t* n_floats) { CpuScene* s = (CpuScen
 
 void flatcpu_closest_hit(void* h, const hrt_params* pr, int64_t n, const float* ro, const float* rd, float t_min, float t_max,
                          uint32_t pixel0, hrt_hit* out) {
-    const DScene& sc = ((CpuScene*)h)->ds;
+    DScene sc = ((CpuScene*)h)->ds;
+    sc.stale_ff = 1;      // as k_hits: the record always carries the inherited frontFace
     std::vector<int> stack(HRT_STACK_DEPTH * HRT_BLOCK);
     for (int64_t i = 0; i < n; ++i) {
         const vec3 o(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
@@ -74,8 +76,8 @@ void flatcpu_closest_hit(void* h, const hrt_params* pr, int64_t n, const float* 
         hh.prim = wh.prim; hh.tri = -1;
         if (wh.prim >= 0) {
             DRec rec;
-            world_rec(sc, wh, o, d, pr->quirks, t_min, rec);
-            hh.t = rec.t; hh.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? wh.sub : -1; hh.front_face = rec.frontFace ? 1 : 0;
+            hit_record(sc, wh, o, d, pr->quirks, t_min, rec);
+            hh.t = rec.t; hh.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? (wh.sub & ~(HRT_SUB_WRAPPERLESS | HRT_SUB_STALE_BACK)) : -1; hh.front_face = rec.frontFace ? 1 : 0;
             hh.p[0] = rec.p.x; hh.p[1] = rec.p.y; hh.p[2] = rec.p.z;
             hh.normal[0] = rec.normal.x; hh.normal[1] = rec.normal.y; hh.normal[2] = rec.normal.z;
             hh.u = rec.u; hh.v = rec.v;
