@@ -61,7 +61,7 @@ inline uint64_t fastdiv_magic(uint32_t d) { return d <= 1 ? 0 : (uint64_t)(~0ull
 struct DeviceCounters {      // 64-bit accumulators in device memory
     unsigned long long rays, samples, box_tests, tri_tests, mesh_hits, env_lookups;
     unsigned long long trav_box_tests, trav_tri_tests;   // the share of box_tests / tri_tests counted inside k_wf_ext launches
-#ifdef HRT_EXT_PROFILE       // experiments (tests/tools/ext_profile_run.py): where the lanes of k_wf_ext are, phase by phase
+#if defined(HRT_EXT_PROFILE) || defined(HRT_SHADE_PROFILE)       // experiments (tests/tools/ext_profile_run.py): where the lanes of k_wf_ext are, phase by phase
     unsigned long long prof[12];
 #endif
 };
@@ -807,8 +807,17 @@ __device__ HRT_WAVE_FN void wf_ref_consume(const RefMesh& rm, const hrt_params& 
         }
     }
 }
-#ifdef HRT_EXT_PROFILE
+#if defined(HRT_EXT_PROFILE) || defined(HRT_SHADE_PROFILE)
 __device__ DeviceCounters* g_prof_counters;
+#endif
+#ifdef HRT_SHADE_PROFILE     // experiments: wave-cycles of k_wf_shade by phase (s_memtime at the phase boundaries)
+#define HRT_SP_DECL unsigned long long sp_t_ = __builtin_readcyclecounter(), sp_acc_[6] = {0, 0, 0, 0, 0, 0}
+#define HRT_SP_MARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); sp_acc_[k] += n_ - sp_t_; sp_t_ = n_; }
+#define HRT_SP_FLUSH() if (lane == 0) for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_prof_counters->prof[k_], sp_acc_[k_])
+#else
+#define HRT_SP_DECL
+#define HRT_SP_MARK(k)
+#define HRT_SP_FLUSH()
 #endif
 template <bool STATS, class NextRange>
 __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, int mesh_prim, int par, const WfBuf& w, int* stack, unsigned lane,
@@ -965,6 +974,7 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
     const int par = round & 1, nxt = par ^ 1;
     const unsigned base = task * w.T;
     unsigned out = base, qpos = base, rcount = 0;
+    HRT_SP_DECL;
     for (unsigned j0 = 0; j0 < n; j0 += 64) {
         const unsigned pos = base + j0 + lane;
         float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
@@ -988,6 +998,7 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
             wh.prim = prim; wh.sub = sub; wh.t = closest;
             missed = prim < 0;
         }
+        HRT_SP_MARK(0);
         {   // escaped paths: queue them; evaluate the background 64 at a time
             const unsigned long long mm = __ballot(missed);
             if (mm) {
@@ -1001,6 +1012,7 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
                 if (mq.count >= 64) missq_flush<STATS>(sc, w, mq, lane, 64, pc);
             }
         }
+        HRT_SP_MARK(1);
         if (j0 + lane < n && !missed) {
             const bool ended = path_shade<STATS>(sc, pr, ctx, ps, wh, pc);
             if (ended) w.rad[slot] = make_float4(ps.result.x, ps.result.y, ps.result.z, 0.0f);
@@ -1015,6 +1027,7 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
             }
         }
         const unsigned long long ma = __ballot(alive);
+        HRT_SP_MARK(2);
         int enq = HRT_ENQ_NONE;
         MeshRay mr;
         float closest = __builtin_huge_valf();
@@ -1026,9 +1039,12 @@ __device__ HRT_WAVE_FN void wf_shade_task(const DScene& sc, const hrt_params& pr
             enq = wf_prepare<STATS>(sc, pr, 0, ws.first_mesh, ws.has_mesh ? ws.first_mesh : -1, ps.o, ps.d, ctx, closest, prim, sub, mr, n_culled);
             wf_store_state(w, nxt, npos, ps, closest, slot, prim, sub);
         }
+        HRT_SP_MARK(3);
         out += (unsigned)__popcll(ma);
         wf_enqueue(w, enq, mr, closest, npos, lt, qpos, base + w.T - 1, rcount);
+        HRT_SP_MARK(4);
     }
+    HRT_SP_FLUSH();
     live_out = out - base; qn_out = qpos - base; rn_out = rcount;
 }
 // what a shading wave adds to the device counters when it is done
@@ -1057,6 +1073,9 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
     const unsigned long long lt = (1ull << lane) - 1ull;
     __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
     __shared__ float s_missq[4][7 * HRT_MISSQ_CAP];
+#ifdef HRT_SHADE_PROFILE
+    g_prof_counters = counters;
+#endif
     stage_tables(sc, s_tables);
     MissQueue mq;
     mq.f = s_missq[threadIdx.x >> 6]; mq.slot = (unsigned*)(mq.f + 6 * HRT_MISSQ_CAP); mq.count = 0;
@@ -1895,6 +1914,13 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     DeviceCounters c;
     HIPCHK(hipMemcpy(&c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
+#ifdef HRT_SHADE_PROFILE
+    if (c.prof[0]) {
+        double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)c.prof[k];
+        fprintf(stderr, "[shade profile] wave-cycles: load+trailing prims %.1f %% | miss queue %.1f %% | hitRecord+scatter %.1f %% | next-segment prepare %.1f %% | stores+enqueue %.1f %% (total %.3g)\n",
+                100.0 * c.prof[0] / tot, 100.0 * c.prof[1] / tot, 100.0 * c.prof[2] / tot, 100.0 * c.prof[3] / tot, 100.0 * c.prof[4] / tot, tot);
+    }
+#endif
 #ifdef HRT_EXT_PROFILE
     if (c.prof[0]) {
         const double in_steps = (double)c.prof[1], lf = (double)c.prof[3];
