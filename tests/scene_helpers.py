@@ -60,7 +60,7 @@ def soup_scene(tmp_path, kind, scale=1.0, offset=(0.0, 0.0, 0.0), n=300, seed=7)
 
 
 def _v3(v): return "[%.9g, %.9g, %.9g]" % tuple(v)
-def random_world(tmp_path, seed, extreme, meshes=False, images=False):
+def random_world(tmp_path, seed, extreme, meshes=False, images=False, bare_glass=False):
     """A random world of analytic primitives (spheres, rects, boxes, media, free triangles) on a 0.5 lattice, so that
     coplanar / coincident surfaces are common, with random transform chains and materials and a few objects listed twice
     with another material (exact ties between primitives).  `extreme` adds degenerate parameters: zero / negative radii and
@@ -69,7 +69,9 @@ def random_world(tmp_path, seed, extreme, meshes=False, images=False):
     aligned grid that is coplanar with rects and box faces) at random places of the object list, under wrapper chains of their
     own: the wavefront pipeline walks the list mesh by mesh, analytic primitives in between (k_wf_pre).  `images` adds a
     7x5 PNG image texture (as albedo and as roughness) and a 16x8 Radiance environment map as background, so texel fetches
-    see the (u, v) every primitive kind produces -- including the NaN and out-of-range ones of degenerate primitives."""
+    see the (u, v) every primitive kind produces -- including the NaN and out-of-range ones of degenerate primitives.
+    `bare_glass` (with `meshes`): half of the meshes stand in the list without a wrapper and get a dielectric material -- their
+    hits inherit hitRecord::frontFace from the previous object of the walk (hrt_device.h WorldHit)."""
     import re
     import numpy as np
     d = tmp_path
@@ -167,12 +169,15 @@ def random_world(tmp_path, seed, extreme, meshes=False, images=False):
                         for b in range(g):
                             i0 = a * (g + 1) + b + 1
                             f.write("f %d//1 %d//1 %d//1\nf %d//1 %d//1 %d//1\n" % (i0, i0 + 1, i0 + g + 2, i0, i0 + g + 2, i0 + g + 1))
-            objs.insert(int(rm.integers(0, len(objs) + 1)), "  - type: mesh\n    path: fmesh%d.obj\n    material: %s\n" % (i, names[int(rm.integers(0, 8))]) + xfm())
+            mesh_obj = "  - type: mesh\n    path: fmesh%d.obj\n    material: %s\n" % (i, names[int(rm.integers(0, 8))]) + xfm()
+            if bare_glass and np.random.default_rng(3 * 10**6 + 7 * seed + i).random() < 0.5:
+                mesh_obj = "  - type: mesh\n    path: fmesh%d.obj\n    material: bareglass\n" % i
+            objs.insert(int(rm.integers(0, len(objs) + 1)), mesh_obj)
     cam=r.uniform(-1,1,3)*np.array([3,2,1])+np.array([0,1,7])
     y=("film:\n    width: 40\n    height: 40\n    samples: 4\n    output: o.png\n"
        f"camera:\n    position: {_v3(cam)}\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 45\n    aperture: %.6g\n    focal_distance: 7\n    background: {_v3(col())}\n"%r.choice([0,0.1])+
        "textures:\n  - name: chk\n    type: checkered\n    even: [0.9, 0.9, 0.9]\n    odd: [0.1, 0.3, 0.1]\n"
-       "materials:\n"+"".join(mats)+"objects:\n"+"".join(objs))
+       "materials:\n"+"".join(mats)+("  - name: bareglass\n    type: dielectric\n    ior: 1.5\n" if bare_glass else "")+"objects:\n"+"".join(objs))
     if images:
         from hobbyraytracer_amd import api
         ri = np.random.default_rng(2 * 10**6 + seed)

@@ -13,7 +13,7 @@ bad = 0; ran = 0; t0 = time.time()
 for extreme in (0, 1):
     for meshes in (True, False):
         for seed in range(lo, hi):
-            path = random_world(d, 5000 + seed, extreme, meshes=meshes, images=(seed % 2 == 1))
+            path = random_world(d, 5000 + seed, extreme, meshes=meshes, images=(seed % 2 == 1), bare_glass=(seed % 3 == 0))
             os.dup2(devnull, 1)
             msg = None
             try:
