@@ -259,7 +259,9 @@ typedef struct hrt_hit {          /* hitRecord (hittable.h:8-25) as seen by rayC
     float t;
     int32_t prim;                 /* -1 = miss */
     int32_t tri;                  /* triangle index within the mesh, -1 otherwise */
-    int32_t front_face;
+    int32_t front_face;           /* hittable.h:19.  Under quirk Q-3 a mesh hit never writes it (triangle.cpp:118-128): for a mesh
+                                     that stands in the world list without a wrapper it is the flag of the previous successful object
+                                     of HittableList::hit's walk (hittableList.cpp:6-16), `1` when there was none */
     float p[3];
     float normal[3];
     float u, v;
