@@ -1219,6 +1219,10 @@ hrt_status fail_hip(hipError_t e, const char* what) {
     return HRT_ERR_HIP;
 }
 hrt_status fail(hrt_status s, const std::string& msg) { g_err = msg; return s; }
+}  // namespace
+// (for the library's other translation unit, hrt_lbvh.hip; not part of the ABI)
+extern "C" __attribute__((visibility("hidden"))) void hrt_set_last_error(const char* msg) { g_err = msg; }
+namespace {
 
 #define HIPCHK(expr)                                         \
     do {                                                     \

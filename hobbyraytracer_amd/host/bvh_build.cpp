@@ -241,6 +241,13 @@ std::vector<float> referenceLeafBoxes(const TriangleSoup& soup, std::vector<uint
     return out;
 }
 
+namespace {
+typedef hrt_status (*DeviceBuildFn)(int, const float*, uint32_t, uint32_t, hrt_bvh_node*, uint32_t*, uint32_t*, int32_t*);
+DeviceBuildFn g_deviceBuild = nullptr;
+int g_deviceBuildDevice = 0;
+}  // namespace
+void setDeviceBvhBuilder(void* fn, int device) { g_deviceBuild = (DeviceBuildFn)fn; g_deviceBuildDevice = device; }
+
 BVHNode::BVHNode(TriangleSoup& soup) {
     const size_t n = soup.size();
     if (n >= (1u << 28)) throw FlattenError(HRT_ERR_UNSUPPORTED, "mesh has too many triangles");
@@ -254,6 +261,30 @@ BVHNode::BVHNode(TriangleSoup& soup) {
     SahBuilder sb;
     // tuning knobs (experiments only; the defaults are what the tests and the bench use)
     if (const char* e = std::getenv("HRT_BVH_MAX_LEAF")) sb.maxLeaf = std::min(8, std::max(1, std::atoi(e)));
+    if (g_deviceBuild && n > (size_t)sb.maxLeaf) {
+        // the tree from the GPU (csrc/hrt_lbvh.hip): topology, leaf order, boxes and depth come back finished
+        std::vector<hrt_bvh_node> dn(n - 1);
+        std::vector<uint32_t> order(n);
+        uint32_t nNodes = 0; int32_t dDepth = 0;
+        const hrt_status st = g_deviceBuild(g_deviceBuildDevice, soup.pos.data(), (uint32_t)n, (uint32_t)sb.maxLeaf, dn.data(), &nNodes, order.data(), &dDepth);
+        if (st != HRT_OK) throw FlattenError(st, "the device BVH builder failed (hrt_last_error() of libhrt_hip.so has the reason)");
+        if (dDepth > 31 || nNodes == 0) throw FlattenError(HRT_ERR_UNSUPPORTED, "the LBVH of this mesh is deeper than the traversal stack (31 levels): use the SAH builder");
+        dn.resize(nNodes);
+        TriangleSoup re;
+        re.pos.resize(9 * n); re.nrm.resize(9 * n); re.uv.resize(6 * n);
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t src = order[i];
+            if (src >= n) throw FlattenError(HRT_ERR_INVALID, "the device BVH builder returned a bad leaf order");
+            std::memcpy(&re.pos[9 * i], &soup.pos[9 * src], 36);
+            std::memcpy(&re.nrm[9 * i], &soup.nrm[9 * src], 36);
+            std::memcpy(&re.uv[6 * i], &soup.uv[6 * src], 24);
+        }
+        soup = std::move(re);
+        nodes = std::move(dn);
+        leafBoxes = referenceLeafBoxes(soup, refOrder);
+        depth = dDepth;
+        return;
+    }
     if (const char* e = std::getenv("HRT_BVH_TRI_COST")) sb.triCost = (float)std::atof(e);
     sb.refs.resize(n);
     for (size_t i = 0; i < n; ++i) {

@@ -267,6 +267,8 @@ struct TriangleSoup {
 
 // bvh.h — the flattened replacement of the pointer tree: 64-byte two-child
 // nodes over a triangle soup that is reordered into leaf order.
+// hrt_host_set_bvh_builder (include/hrt_host.h): fn = hrt_host_bvh_build_fn or nullptr
+void setDeviceBvhBuilder(void* fn, int device);
 class BVHNode : public Hittable {
 public:
     BVHNode() {}

@@ -111,6 +111,7 @@ hrt_status hrt_host_camera(const hrt_host_scene* s, int32_t width, int32_t heigh
         return HRT_OK;
     });
 }
+void hrt_host_set_bvh_builder(hrt_host_bvh_build_fn fn, int device) { hrthost::setDeviceBvhBuilder((void*)fn, device); }
 int32_t hrt_host_bvh_depth(const hrt_host_scene* s, int32_t mesh) {
     if (!s || mesh < 0 || (size_t)mesh >= s->mesh_depth.size()) return -1;
     return s->mesh_depth[mesh];

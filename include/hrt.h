@@ -267,6 +267,15 @@ typedef struct hrt_hit {          /* hitRecord (hittable.h:8-25) as seen by rayC
     float u, v;
 } hrt_hit;
 
+/* The culling tree of one mesh, built on `device`: a Morton-ordered LBVH (csrc/hrt_lbvh.hip).  Stands where the reference has
+ * the BVHNode constructor (bvh.cpp:6-61) -- for the TOPOLOGY only, like the host's binned-SAH builder (host/bvh_build.cpp): the
+ * closest hit does not depend on it.  tri_pos: 9 floats per triangle (host memory), finite; max_leaf in 1..8, n_tris > max_leaf.
+ * Out (host memory, caller-allocated): nodes_out[n_tris - 1] (hrt_bvh_node, root = 0, child boxes = padded ITriangle boxes
+ * (triangle.cpp:133-151) united and widened by the kernels' rounding guard), *n_nodes_out, order_out[n_tris] = the triangle at each
+ * position of the leaf order the nodes' leaf codes refer to, *depth_out = inner-node levels (the traversal's stack need). */
+hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
+                                uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out);
+
 typedef struct hrt_scene hrt_scene;   /* device-resident flattened scene */
 
 hrt_status hrt_device_count(int* n);

@@ -123,6 +123,26 @@ def test_cli_rccl_flag_gives_the_same_image(built, assets, scenes_dir, tmp_path)
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_cli_bvh_lbvh_gives_the_same_image_with_fixed_quirks(built, assets, scenes_dir, tmp_path):
+    """`--bvh lbvh`: the meshes' culling trees come from the GPU builder (hrt_bvh_build_device).  The film does not depend on the
+    culling tree (fixed quirks: under the reference's, self-hit winners follow the reference tree over the soup in leaf order)."""
+    from hobbyraytracer_amd import api
+    import shutil
+    for f in ("teapot.obj", "old_hall_4k.hdr"):
+        shutil.copy(os.path.join(assets, f), tmp_path / f)
+    shutil.copy(f"{scenes_dir}/teapot_scene.yaml", tmp_path / "s.yaml")
+    outs = []
+    for extra in (["--bvh", "sah"], ["--bvh", "lbvh"]):
+        name = extra[1] + ".png"
+        p = subprocess.run([api.CLI_PATH, "s.yaml", "--size", "64x48", "--spp", "4", "--quirks", "fixed", "--out", name, *extra], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 1, p.stderr
+        outs.append(api.read_png(str(tmp_path / name)))
+    assert np.array_equal(outs[0], outs[1])
+    p = subprocess.run([api.CLI_PATH, "s.yaml", "--bvh", "octree"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 255 and "sah or lbvh" in p.stderr
+
+
 def test_bench_under_torchrun_two_ranks_on_one_gpu(built, assets, scenes_dir, tmp_path):
     """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run, one process per rank,
     rendezvous on 127.0.0.1), here with 2 ranks sharing the one GPU of the box and gloo as the collective backend (RCCL

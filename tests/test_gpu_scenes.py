@@ -564,3 +564,117 @@ def test_wrapperless_glass_mesh_inherits_the_front_face_of_the_previous_object(b
             assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits), (q, tail, mega, slots)
             assert films_equal(img, ref), (q, tail, mega, slots)
     dev.close()
+
+
+def _lbvh_check(pos, nodes, order, depth, max_leaf):
+    """Walks the tree hrt_bvh_build_device returned: every position of the leaf order in exactly one leaf, leaves of at most
+    max_leaf triangles, child boxes = the padded ITriangle boxes below, united and widened by host/bvh_build.cpp's rounding guard
+    (bit for bit), depth = inner levels."""
+    n = pos.shape[0]
+    assert sorted(order.tolist()) == list(range(n))
+    p = pos[order].reshape(n, 3, 3)
+    lo = p.min(1) - np.float32(1e-4); hi = p.max(1) + np.float32(1e-4)
+    f = nodes.view(np.float32); ch = nodes.view(np.int32)
+    seen = np.zeros(n, dtype=np.int32)
+    # [c0_min_x, c0_max_x, c0_min_y, c0_max_y, c1_min_x, c1_max_x, c1_min_y, c1_max_y, c0_min_z, c0_max_z, c1_min_z, c1_max_z, child0, child1]
+    cols = {0: ((0, 2, 8), (1, 3, 9)), 1: ((4, 6, 10), (5, 7, 11))}
+    visited = np.zeros(len(nodes), dtype=bool)
+
+    def guard(mn, mx):
+        g = np.float32(1e-6) + np.float32(4e-7) * np.maximum(np.abs(mn), np.abs(mx))
+        return (mn - g).astype(np.float32), (mx + g).astype(np.float32)
+
+    def walk(ref):      # -> (box min, box max, first, last, depth)
+        if ref < 0:
+            enc = ~ref
+            first, cnt = enc >> 3, (enc & 7) + 1
+            assert cnt <= max_leaf and first + cnt <= n
+            seen[first:first + cnt] += 1
+            return lo[first:first + cnt].min(0), hi[first:first + cnt].max(0), first, first + cnt - 1, 0
+        assert 0 <= ref < len(nodes) and not visited[ref]
+        visited[ref] = True
+        out = []
+        for c in (0, 1):
+            mn, mx, a, b, d = walk(int(ch[ref, 12 + c]))
+            gmn, gmx = guard(mn, mx)
+            assert np.array_equal(f[ref, list(cols[c][0])].view(np.uint32), gmn.view(np.uint32)), (ref, c)
+            assert np.array_equal(f[ref, list(cols[c][1])].view(np.uint32), gmx.view(np.uint32)), (ref, c)
+            out.append((mn, mx, a, b, d))
+        assert out[0][3] + 1 == out[1][2]                      # the children's ranges are adjacent, left first
+        return np.minimum(out[0][0], out[1][0]), np.maximum(out[0][1], out[1][1]), out[0][2], out[1][3], 1 + max(out[0][4], out[1][4])
+
+    import sys
+    sys.setrecursionlimit(10000)
+    _, _, a, b, d = walk(0)
+    assert (a, b) == (0, n - 1) and (seen == 1).all() and visited.all() and d == depth
+    return d
+
+
+def test_device_bvh_builder_structure(built, tmp_path):
+    """hrt_bvh_build_device (csrc/hrt_lbvh.hip): a Morton-ordered LBVH built on the GPU.  Structure, boxes and depth on the
+    teapot, on soups with coincident centroids (equal Morton codes: ties are split by position) and on the smallest inputs."""
+    from hobbyraytracer_amd import api
+    api.write_teapot_obj(str(tmp_path / "teapot.obj"), 1.0)
+    hs = api.HostScene(_one_mesh_scene(tmp_path, "teapot.obj"), str(tmp_path))
+    m, (pos, _, _) = hs.flat.meshes[0], hs.mesh_arrays(0)
+    cases = [("teapot", np.asarray(pos, dtype=np.float32).reshape(-1, 9))]
+    r = np.random.default_rng(2)
+    cases.append(("soup", (r.uniform(-1, 1, (5000, 1, 3)) + r.normal(scale=0.05, size=(5000, 3, 3))).astype(np.float32).reshape(-1, 9)))
+    same = np.tile(r.uniform(-1, 1, (1, 9)).astype(np.float32), (300, 1))                      # 300 copies of one triangle
+    cases.append(("copies", same))
+    cases.append(("copies+1", np.concatenate([same, r.uniform(-5, 5, (1, 9)).astype(np.float32)])))
+    for k in (3, 4, 5, 9):
+        cases.append((f"n={k}", r.uniform(-1, 1, (k, 9)).astype(np.float32)))
+    cases.append(("flat", np.concatenate([r.uniform(-1, 1, (2000, 3, 2)), np.zeros((2000, 3, 1))], 2).astype(np.float32).reshape(-1, 9)))
+    for name, tri in cases:
+        for max_leaf in (1, 2, 4):
+            if tri.shape[0] <= max_leaf: continue
+            nodes, order, depth = api.bvh_build_device(tri, max_leaf)
+            d = _lbvh_check(tri, nodes, order, depth, max_leaf)
+            assert d <= 31, (name, d)
+    with pytest.raises(api.HrtError):
+        api.bvh_build_device(np.zeros((2, 9), np.float32), 2)                 # nothing to build: the host wraps such a mesh in one leaf
+    bad = cases[1][1].copy(); bad[7, 3] = np.nan
+    with pytest.raises(api.HrtError):
+        api.bvh_build_device(bad, 2)
+
+
+def _one_mesh_scene(tmp_path, obj):
+    (tmp_path / "one.yaml").write_text(
+        "film:\n    width: 32\n    height: 32\n    samples: 4\n    output: o.png\n"
+        "camera:\n    position: [0, 2, 9]\n    look_at: [0, 1, 0]\n    up: [0, 1, 0]\n    fov: 40\n    aperture: 0\n    focal_distance: 9\n"
+        "    background: [0.6, 0.7, 0.9]\n"
+        "materials:\n  - name: a\n    type: lambertian\n    albedo: [0.8, 0.4, 0.3]\n"
+        "objects:\n  - type: mesh\n    path: %s\n    material: a\n" % obj)
+    return str(tmp_path / "one.yaml")
+
+
+def test_device_bvh_builder_renders_like_the_host_builder(built, assets, scenes_dir):
+    """The film does not depend on the culling tree: with the LBVH from the GPU the fixed-quirks film of the teapot scene is
+    the SAH tree's bit for bit, and with the reference's quirks (whose self-hit winners follow the reference tree restated
+    over the soup in LEAF order, which moves with the builder) it is the oracle's on the same flattened scene."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    W = H = 96
+    p_fixed = api.default_params(W, H, 8, quirks=api.QUIRKS_FIXED, stats=True)
+    hs0 = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    dev0 = api.DeviceScene(hs0.flat_ptr, 0)
+    sah, s_sah = dev0.render_tile(hs0.camera(W, H), p_fixed)
+    dev0.close()
+    api.use_device_bvh_builder(True)
+    try:
+        hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    finally:
+        api.use_device_bvh_builder(False)
+    assert hs.flat.n_nodes != hs0.flat.n_nodes or hs.bvh_depth(0) != hs0.bvh_depth(0)       # another tree
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    cam = hs.camera(W, H)
+    img, st = dev.render_tile(cam, p_fixed)
+    assert np.array_equal(img.view(np.uint32), sah.view(np.uint32)) and st.rays == s_sah.rays
+    assert st.box_tests > s_sah.box_tests                                                       # ... a looser one
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(W, H, 8, quirks=q, stats=True))
+        for mega in (False, True):
+            img, st = dev.render_tile(cam, api.default_params(W, H, 8, quirks=q, stats=True, megakernel=mega))
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == sr.rays, (q, mega)
+    dev.close()
