@@ -69,12 +69,12 @@ template <class T> inline const T* uniform_table(const T* p) { return p; }
 
 #define HRT_TABLE_LDS_BYTES 12288
 #if defined(__HIPCC__)
-// Copies prims / mats / texs / meshes into `buf` (HRT_TABLE_LDS_BYTES of LDS, 16-byte aligned) when they
+// Copies prims / mats / texs / meshes into `buf` (`budget` bytes of LDS, 16-byte aligned) when they
 // fit, and repoints sc.l*; every thread of the block must call it (it ends with a barrier).
-__device__ inline void stage_tables(DScene& sc, uint32_t* buf) {
+__device__ inline void stage_tables(DScene& sc, uint32_t* buf, uint32_t budget = HRT_TABLE_LDS_BYTES) {
     const uint32_t wp = (uint32_t)(sc.n_prims * sizeof(hrt_prim) + 15) / 16 * 4, wm = (uint32_t)(sc.n_mats * sizeof(hrt_material) + 15) / 16 * 4;
     const uint32_t wt = (uint32_t)(sc.n_texs * sizeof(hrt_texture) + 15) / 16 * 4, wx = (uint32_t)(sc.n_meshes * sizeof(hrt_mesh) + 15) / 16 * 4;
-    if ((wp + wm + wt + wx) * 4u <= HRT_TABLE_LDS_BYTES) {
+    if ((wp + wm + wt + wx) * 4u <= budget) {
         const uint32_t* src[4] = {(const uint32_t*)sc.prims, (const uint32_t*)sc.mats, (const uint32_t*)sc.texs, (const uint32_t*)sc.meshes};
         const uint32_t words[4] = {(uint32_t)(sc.n_prims * sizeof(hrt_prim)) / 4, (uint32_t)(sc.n_mats * sizeof(hrt_material)) / 4,
                                    (uint32_t)(sc.n_texs * sizeof(hrt_texture)) / 4, (uint32_t)(sc.n_meshes * sizeof(hrt_mesh)) / 4};

@@ -1100,16 +1100,22 @@ __global__ __launch_bounds__(256, HRT_SHADE_WAVES) void k_wf_shade(DScene sc, hr
 // CU's L1) orders them.
 #define HRT_TAIL_MAX_MESHES 4
 struct TailMeshes { int n; int prim[HRT_TAIL_MAX_MESHES]; };
+// Residency is what this kernel lives on (a task's rounds are one long dependency chain; the more tasks run at once, the fewer
+// wait for a wave): four blocks per CU with the 20- and 24-entry stacks -- 128 VGPRs (12 bytes of scratch) and a table
+// budget cut to what is left of the LDS beside stack and miss queue (4 KB / 1.5 KB: the headline scene's tables take 1.3 KB;
+// larger tables stay in global memory) -- three with the 32-entry stack.  One rank's 1/8 share of the headline frame:
+// 10.9 -> 10.0 ms against three blocks with 12 KB tables, 9.7 ms with the switch into this kernel moved from round 20 to 8.
 template <bool STATS, int DEPTH>
-__global__ __launch_bounds__(256, 2) void k_wf_tail(DScene sc, hrt_params pr, RenderMap map, WfScene ws, TailMeshes tm, unsigned n_local, int s0, int round0,
+__global__ __launch_bounds__(256, DEPTH <= 24 ? 4 : 3) void k_wf_tail(DScene sc, hrt_params pr, RenderMap map, WfScene ws, TailMeshes tm, unsigned n_local, int s0, int round0,
                                                     int rounds_end, WfBuf w, DeviceCounters* counters, int leaf_num) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     __shared__ int s_stack[DEPTH * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t s_tables[HRT_TABLE_LDS_BYTES / 4];
+    constexpr uint32_t TABLE_BYTES = DEPTH <= 20 ? 4096 : (DEPTH <= 24 ? 1536 : 4096);
+    __shared__ __attribute__((aligned(16))) uint32_t s_tables[TABLE_BYTES / 4];
     __shared__ float s_missq[4][7 * HRT_MISSQ_CAP];
-    stage_tables(sc, s_tables);
+    stage_tables(sc, s_tables, TABLE_BYTES);
     MissQueue mq;
     mq.f = s_missq[threadIdx.x >> 6]; mq.slot = (unsigned*)(mq.f + 6 * HRT_MISSQ_CAP); mq.count = 0;
     unsigned n_seg = 0, n_culled = 0;
@@ -1533,12 +1539,13 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     int ext_per_cu_env = 0;                              // experiments: k_wf_ext blocks per CU
     if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu_env = std::min(10, std::max(1, atoi(e)));
     // from which round on a task's remaining rounds run in one k_wf_tail launch (>= D: never)
-    // Measured (tests/tools/stripe_scaling.py, sweep_env.py): on the full headline frame every switch point loses (49.1 ms
-    // without, 51.5 at round 20, 60.0 with the tail alone), on its 1/8 share round 20 wins 5 % (10.1 -> 9.65 ms).
+    // Measured (tests/tools/stripe_scaling.py, sweep_env.py; round 2, k_wf_tail at four blocks per CU): on the full headline
+    // frame and its half every switch point loses or ties (51.5 ms without, 51.5 at round 40, 52.4 at 24), on the 1/4 share
+    // round 24 wins 4 % (18.5 -> 17.8 ms), on the 1/8 share rounds 2..8 win 11 % (10.9 -> 9.7 ms; 10.1 at round 20).
     // Tiny batches (previews: <= 512 Ki slots) are nothing but launch and wait: the tail from round 1 renders 64x64x4 in
     // 2.2 instead of 2.9 ms.
     const size_t batch_slots = (size_t)n_local * (size_t)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local));
-    int tail_round = batch_slots <= ((size_t)512 << 10) ? 1 : (batch_slots <= ((size_t)6 << 20) ? 20 : D);
+    int tail_round = batch_slots <= ((size_t)512 << 10) ? 1 : (batch_slots <= ((size_t)6 << 20) ? 8 : (batch_slots <= ((size_t)12 << 20) ? 24 : D));
     if (const char* e = getenv("HRT_WF_TAIL_ROUND")) tail_round = std::max(1, atoi(e));
     if (n_mesh > HRT_TAIL_MAX_MESHES) tail_round = D;
     const bool stale_ff = sc->ds.stale_ff && (pr->quirks & HRT_Q3_TRI_NO_FACE);
@@ -1623,7 +1630,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
             int need = 0;
             for (int m = 0; m < n_mesh; ++m) { tm.prim[m] = sc->mesh_prims[m]; need = std::max(need, sc->mesh_depths[m]); }
             const int variant = need <= 20 ? 20 : (need <= 24 ? 24 : 32);
-            const int tail_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * (variant == 32 ? 2 : 3));   // 46..58 KB of LDS per block
+            const int tail_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * (variant == 32 ? 3 : 4));   // 38..50 KB of LDS per block
             next_counters((unsigned)tail_blocks * 4u);
             w.ref_prod = ref_block(D, 0); w.ref_cons = ref_block(D, 0);
 #define HRT_LAUNCH_TAIL(S, DP) hipLaunchKernelGGL((k_wf_tail<S, DP>), dim3(tail_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, tm, n_local, s0, tail_round, D, w, sc->d_counters, leaf_num)
