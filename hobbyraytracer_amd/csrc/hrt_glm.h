@@ -23,7 +23,7 @@
 // (Cephes single-precision forms) for the same reason: glibc, MSVC's CRT and
 // ROCm's ocml all differ in the last ulp, so "the reference's libm" is not a
 // single function anyway.  tests/test_glm_math.py bounds their error against
-// numpy (<= 4 ulp) on the CPU, and tests/test_gpu_math.py checks CPU == GPU
+// numpy (<= 4 ulp) on the CPU, and tests/test_gpu_parity.py::test_math_kernels_bit_exact checks CPU == GPU
 // bit for bit.
 #pragma once
 
