@@ -664,14 +664,24 @@ __device__ inline void mesh_grid(const DScene& sc, int mi, float4& origin, float
 // One inner-node step: tests both children of node ts.cur, descends / pushes / pops.
 template <bool STATS>
 __device__ inline void trav_inner(const uint4* __restrict__ nodes, const MeshRay& r, TravState& ts, float t_lo, int* stack,
-                                  DCounters& cnt) {
+                                  DCounters& cnt, unsigned long long* stp = nullptr) {
     const int cur = ts.cur;
     const uint4 A = nodes[2 * cur + 0];
     const uint4 B = nodes[2 * cur + 1];
+#ifdef HRT_STEP_PROFILE      // experiments: where a node step's cycles go (s_memtime after forced waits; see tests/tools/step_profile_run.py)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { const unsigned long long n_ = __builtin_readcyclecounter(); stp[0] += n_ - stp[3]; stp[3] = n_; stp[6] += 1; }
+#endif
     if (STATS) cnt.box_tests += 2;
     float tn0, tn1; bool h0, h1;
     node_test(A, B, r, t_lo, ts.closest, tn0, h0, tn1, h1);
     const int ch0 = (int)A.w, ch1 = (int)B.w;
+#ifdef HRT_STEP_PROFILE
+    {   // (the compare results must exist before the clock is read)
+        asm volatile("" :: "v"(tn0), "v"(tn1), "s"(__ballot(h0)), "s"(__ballot(h1)));
+        const unsigned long long n_ = __builtin_readcyclecounter(); stp[1] += n_ - stp[3]; stp[3] = n_;
+    }
+#endif
     if (h0 && h1) {
         const bool swap = tn1 < tn0;
         const int nearc = swap ? ch1 : ch0, farc = swap ? ch0 : ch1;
@@ -681,6 +691,12 @@ __device__ inline void trav_inner(const uint4* __restrict__ nodes, const MeshRay
     else if (h1) ts.cur = ch1;
     else if (ts.sp > 0) { --ts.sp; ts.cur = stack[ts.sp * HRT_BLOCK]; }
     else ts.cur = HRT_TRAV_DONE;
+#ifdef HRT_STEP_PROFILE
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(ts.cur) : "memory");
+        const unsigned long long n_ = __builtin_readcyclecounter(); stp[2] += n_ - stp[3]; stp[3] = n_;
+    }
+#endif
 }
 
 // One leaf: every triangle of leaf code ts.cur through the exact ITriangle test, then pop.

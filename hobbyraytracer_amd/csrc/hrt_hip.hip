@@ -61,7 +61,7 @@ inline uint64_t fastdiv_magic(uint32_t d) { return d <= 1 ? 0 : (uint64_t)(~0ull
 struct DeviceCounters {      // 64-bit accumulators in device memory
     unsigned long long rays, samples, box_tests, tri_tests, mesh_hits, env_lookups;
     unsigned long long trav_box_tests, trav_tri_tests;   // the share of box_tests / tri_tests counted inside k_wf_ext launches
-#if defined(HRT_EXT_PROFILE) || defined(HRT_SHADE_PROFILE)       // experiments (tests/tools/ext_profile_run.py): where the lanes of k_wf_ext are, phase by phase
+#if defined(HRT_EXT_PROFILE) || defined(HRT_SHADE_PROFILE) || defined(HRT_STEP_PROFILE)       // experiments (tests/tools/ext_profile_run.py): where the lanes of k_wf_ext are, phase by phase
     unsigned long long prof[12];
 #endif
 };
@@ -807,7 +807,7 @@ __device__ HRT_WAVE_FN void wf_ref_consume(const RefMesh& rm, const hrt_params& 
         }
     }
 }
-#if defined(HRT_EXT_PROFILE) || defined(HRT_SHADE_PROFILE)
+#if defined(HRT_EXT_PROFILE) || defined(HRT_SHADE_PROFILE) || defined(HRT_STEP_PROFILE)
 __device__ DeviceCounters* g_prof_counters;
 #endif
 #ifdef HRT_SHADE_PROFILE     // experiments: wave-cycles of k_wf_shade by phase (s_memtime at the phase boundaries)
@@ -832,6 +832,16 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
     unsigned pos = 0;
 #ifdef HRT_EXT_PROFILE
     unsigned prof_[12] = {0};
+#endif
+#ifdef HRT_STEP_PROFILE
+    // PER LANE (the stamps inside trav_inner are taken under the lanes' own control flow): load wait | box tests | descend / stack |
+    // last stamp | votes + loop control (for a lane that sits a step out: the whole step) | wave steps seen | steps taken
+    unsigned long long stp_[7] = {0, 0, 0, 0, 0, 0, 0};
+#define HRT_STP_CTRL() { const unsigned long long n_ = __builtin_readcyclecounter(); stp_[4] += n_ - stp_[3]; stp_[3] = n_; stp_[5] += 1; }
+#define HRT_STP_ARG , stp_
+#else
+#define HRT_STP_CTRL()
+#define HRT_STP_ARG
 #endif
     for (;;) {
         const unsigned long long need = __ballot(!has);
@@ -863,6 +873,9 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
 #ifdef HRT_EXT_PROFILE
         prof_[0] += 1;
 #endif
+#ifdef HRT_STEP_PROFILE
+        stp_[3] = __builtin_readcyclecounter();
+#endif
         for (;;) {
             const unsigned long long m_in = __ballot(has && trav_at_inner(ts));
             if (!m_in) break;
@@ -871,11 +884,13 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
 #ifdef HRT_EXT_PROFILE
             prof_[1] += 1; prof_[2] += (unsigned)__popcll(m_in); prof_[8] += (unsigned)__popcll(__ballot(has));
 #endif
-            if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt);
+            HRT_STP_CTRL();
+            if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt HRT_STP_ARG);
 #ifdef HRT_EXT_PROFILE
             { const unsigned long long m2 = __ballot(has && trav_at_inner(ts)); if (m2) { prof_[1] += 1; prof_[2] += (unsigned)__popcll(m2); prof_[8] += (unsigned)__popcll(__ballot(has)); } }
 #endif
-            if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt);
+            HRT_STP_CTRL();
+            if (has && trav_at_inner(ts)) trav_inner<STATS>(em.nodes, r, ts, t_lo, stack, cnt HRT_STP_ARG);
         }
 #ifdef HRT_EXT_PROFILE
         {
@@ -901,6 +916,13 @@ __device__ HRT_WAVE_FN void wf_ext_run(const ExtMesh& em, const hrt_params& pr, 
 #ifdef HRT_EXT_PROFILE
     if (lane == 0) for (int k = 0; k < 12; ++k) if (prof_[k]) atomicAdd(&g_prof_counters->prof[k], (unsigned long long)prof_[k]);
 #endif
+#ifdef HRT_STEP_PROFILE
+    if (lane == 0) {      // lane 0 speaks for its wave: its own parts over the steps it took, the step length over all steps
+        for (int k = 0; k < 3; ++k) atomicAdd(&g_prof_counters->prof[k], stp_[k]);
+        atomicAdd(&g_prof_counters->prof[6], stp_[6]);
+        atomicAdd(&g_prof_counters->prof[4], stp_[4] + stp_[0] + stp_[1] + stp_[2]); atomicAdd(&g_prof_counters->prof[5], stp_[5]);
+    }
+#endif
 }
 // One launch per round and mesh: persistent waves pull tasks (HRT_TASK_GROUPS) and their rays.
 // DEPTH = entries of the per-lane LDS stack (>= the mesh's BVH depth, checked by the host): shallower trees
@@ -913,7 +935,7 @@ __global__ __launch_bounds__(HRT_BLOCK) __attribute__((amdgpu_waves_per_eu(DEPTH
     const unsigned long long lt = (1ull << lane) - 1ull;
     DCounters cnt; cnt.box_tests = 0; cnt.tri_tests = 0;
     const unsigned wave = HRT_UNIFORM((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-#ifdef HRT_EXT_PROFILE
+#if defined(HRT_EXT_PROFILE) || defined(HRT_STEP_PROFILE)
     g_prof_counters = counters;
 #endif
     if (pr.quirks & HRT_Q4_SHEAR_FROM_ORIGIN)
@@ -1925,6 +1947,14 @@ hrt_status hrt_scene_stats(hrt_scene* sc, hrt_stats* stats) {
     DeviceCounters c;
     HIPCHK(hipMemcpy(&c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(sc->d_counters, 0, sizeof(c)));
+#ifdef HRT_STEP_PROFILE
+    if (c.prof[5] && c.prof[6]) {
+        const double n = (double)c.prof[5], a = (double)c.prof[6], step = c.prof[4] / n, l = c.prof[0] / a, b = c.prof[1] / a, d = c.prof[2] / a;
+        fprintf(stderr, "[step profile] %.4g node steps of a wave in k_wf_ext, lane 0 taking part in %.0f %%; s_memtime ticks per step %.0f = node loads until the data is there %.0f | box tests %.0f | "
+                        "descend / push / pop until the LDS answers %.0f | votes and loop control %.0f  (each part includes one s_memtime round trip)\n",
+                n, 100.0 * a / n, step, l, b, d, step - l - b - d);
+    }
+#endif
 #ifdef HRT_SHADE_PROFILE
     if (c.prof[0]) {
         double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)c.prof[k];

@@ -4,7 +4,10 @@
     cp /tmp/libhrt_hip_prof.so hobbyraytracer_amd/lib/libhrt_hip.so && python3 tests/tools/ext_profile_run.py
 The library prints one "[ext profile]" line per hrt_scene_stats call (stderr).  Round 2, headline frame (640x640x100, 50 rounds):
 10.5 M outer iterations, 107.7 M inner wave-steps with 41 % of the 64 lanes AT an inner node while 87 % hold a ray (the rest wait at
-a postponed leaf or are done), 10.2 M leaf phases with 50 % of the lanes at a leaf (90 % of those leaves hold two triangles)."""
+a postponed leaf or are done), 10.2 M leaf phases with 50 % of the lanes at a leaf (90 % of those leaves hold two triangles).
+With -DHRT_STEP_PROFILE instead (s_memtime stamps inside a node step, after forced waits; lane 0 speaks for its wave; the build spills 60
+bytes, so the parts are what counts, not the total): "[step profile]" -- 2060 ticks per node step of a wave = 1299 until the data of the two
+16-byte node loads is there, 333 box tests, 255 descend / push / pop until the LDS answers, 173 votes and loop control."""
 import os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 from hobbyraytracer_amd import api
