@@ -50,8 +50,18 @@ def test_traversal_kernel_keeps_six_waves_per_simd(usage):
 
 
 def test_no_hot_kernel_spills(usage):
-    for frag in ("8k_wf_extILb0", "10k_wf_shadeILb0", "8k_wf_genILb0", "8k_wf_preILb0", "9k_wf_tailILb0", "11k_pathtraceILb0"):
+    for frag in ("8k_wf_extILb0", "10k_wf_shadeILb0", "8k_wf_genILb0", "8k_wf_preILb0", "9k_wf_tailILb0ELi32", "11k_pathtraceILb0", "10k_wf_stale"):
         for name, u in _find(usage, frag).items():
             assert u["ScratchSize"] == 0, (name, u)
     for name, u in _find(usage, "10k_wf_shadeILb0").items():
         assert u["VGPRs"] <= 128, (name, u)          # 4 waves per SIMD
+
+
+def test_tail_kernel_keeps_four_blocks_per_cu(usage):
+    # k_wf_tail<false, 20 | 24>: residency is what it lives on (one wave per task of a small batch: DESIGN.md 5) -- four blocks of four
+    # waves per CU need <= 128 VGPRs and <= 40 KB of LDS; the register cap costs 12 bytes of scratch, bought knowingly (10.9 -> 10.0 ms on
+    # the 1/8 share of the headline frame); more would say the kernel grew
+    for frag in ("9k_wf_tailILb0ELi20EE", "9k_wf_tailILb0ELi24EE"):
+        for name, u in _find(usage, frag).items():
+            assert u["VGPRs"] <= 128 and u["ScratchSize"] <= 16, (name, u)
+            assert 4 * u["LDS"] <= 160 * 1024, (name, u)
