@@ -288,7 +288,7 @@ def main():
             roof["bound"] = "issue"      # not HBM: see hbm_measured_frac and issue{}
             roof["bound_of_the_algorithmic_figure"] = "hbm"
             roof_note = ("the BVH is L2-resident: measured HBM traffic is %.0f %% of the algorithmic bytes, so 'frac' prices L2-served bytes against "
-                         "the HBM peak and can exceed 1; the kernel is bound by instruction issue and L2 latency, not by HBM (DESIGN.md 4.1)" % (100.0 * traffic / k_bytes))
+                         "the HBM peak and can exceed 1; the kernel is bound by instruction issue and by the latency of its divergent node fetches (63 % of a node step is the wait for two 16-byte loads served by L1 / L2), not by HBM (DESIGN.md 4.1)" % (100.0 * traffic / k_bytes))
         if roof_note:
             result["roofline"]["note"] = roof_note
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
