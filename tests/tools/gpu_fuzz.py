@@ -1,5 +1,6 @@
 """usage (GPU box, repo root): python3 tests/tools/gpu_fuzz.py FIRST LAST -- a fuzz campaign, not a test: random worlds
 (tests/scene_helpers.py random_world; mild and extreme, with and without meshes) on every render path against the oracle.
+HRT_FUZZ_LBVH=1: with the meshes' culling trees built on the GPU (a load that fails because the LBVH is deeper than 31 levels is skipped).
 Failing worlds are copied to gpurun_out/gfuzz/.  About 40 worlds per second."""
 import sys, os, tempfile, pathlib, time; sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -8,6 +9,8 @@ from oracle import oracle_py as orc
 from tests.scene_helpers import random_world
 d = pathlib.Path(tempfile.mkdtemp())
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+if os.environ.get("HRT_FUZZ_LBVH"):           # the meshes' culling trees from the GPU builder (hrt_bvh_build_device) instead of the host's
+    api.use_device_bvh_builder(True)
 devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1)
 bad = 0; ran = 0; t0 = time.time()
 for extreme in (0, 1):
@@ -17,7 +20,11 @@ for extreme in (0, 1):
             os.dup2(devnull, 1)
             msg = None
             try:
-                hs = api.HostScene(path, str(d))
+                try:
+                    hs = api.HostScene(path, str(d))
+                except api.HrtError:
+                    if os.environ.get("HRT_FUZZ_LBVH"): continue
+                    raise
                 try:
                     dev = api.DeviceScene(hs.flat_ptr, 0)
                 except api.HrtError as e:
