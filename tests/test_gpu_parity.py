@@ -290,4 +290,15 @@ def test_headline_frame_at_full_size_against_the_oracle(built, tmp_path):
     same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))     # (NaN payloads differ; film.cpp:35-37 scrubs them)
     assert same.all(), int((~same).any(2).sum())
     assert np.array_equal(dev.resolve_u8(img), orc.resolve_u8(ref))
+    # ... and what the ranks of a 4- and an 8-GPU job render: their shares are small enough to run their later rounds inside
+    # k_wf_tail (from round 24 / 8), which the single-GPU frame never enters
+    for G in (4, 8):
+        out = np.zeros_like(ref)
+        rays = 0
+        for rank in range(G):
+            part, sp = dev.render_stripes(cam, p, 8, rank, G)
+            out[api.stripe_row_indices(H, 8, rank, G)] = part
+            rays += sp.rays
+        same = (out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref))
+        assert same.all() and rays == sr.rays, (G, int((~same).any(2).sum()), rays)
     dev.close()
