@@ -8,6 +8,7 @@ fp32 linear film tiles (RCCL all_gather when N > 1), row permutation and Film re
 on rank 0's copy.  Inputs (scene, BVH, env map) are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (no launcher: starts its own N ranks as a CHILD torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -28,7 +29,36 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# peaks (HBM3E 8.0 TB/s spec; XCD-L2 gather 17 TB/s) live in hobbyraytracer_amd/benchline.py with the roofline arithmetic
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start N ranks as a CHILD process
+    (python -m torch.distributed.run, one process per GPU) BEFORE this process imports torch or touches a GPU --
+    never exec: replacing a process that has initialised the GPU takes the box down -- relay rank 0's JSON line
+    and exit with the child's code."""
+    import socket
+    import subprocess
+    from hobbyraytracer_amd.benchline import last_json_line
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)     # stderr passes through
+    line = last_json_line(p.stdout)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    else:
+        sys.stderr.write(p.stdout[-4000:])
+    if p.returncode != 0:
+        raise SystemExit(p.returncode)
+    if line is None:
+        raise SystemExit("the ranks ended without printing a bench line")
+    raise SystemExit(0)
 
 
 def host_cores():
@@ -80,18 +110,19 @@ def main():
     ap.add_argument("--no-cli-wall-clock", action="store_true", help="skip the one run of the CLI binary behind config.cli_wall_clock_s")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])      # does not return
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from hobbyraytracer_amd import api, tiles
+    from hobbyraytracer_amd import api, benchline, tiles
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
@@ -205,41 +236,17 @@ def main():
             # bytes of exactly those launches (rounds a small batch runs inside k_wf_tail are neither timed nor counted here)
             k_bytes = (32.0 * st_count.traversal_box_tests + 36.0 * st_count.traversal_tri_tests) / k_launches
             k_ms = st.traversal_ms / st.traversal_launches
-        achieved = k_bytes / (k_ms * 1e-3) / 1e9
-        # HBM traffic per launch of that kernel cannot be measured inside this process (PMC counters need their
-        # own rocprofv3 passes); report the figure of the newest committed profile of the same workload, if any.
-        traffic = None
+        # HBM traffic and issue-side counters of that kernel cannot be measured inside this process (PMC counters need their own
+        # rocprofv3 passes): the figures of the newest committed profile of the same workload, if any (profiles/collect.sh)
+        traffic = issue = None
         if W == 640 and H == 640 and spp == 100 and args.scene == "teapot_scene.yaml" and args.quirks == "reference" and world == 1:
-            import glob
-            for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
-                try:
-                    tj = json.load(open(tf))
-                    if tj.get("kernel") == kname:
-                        traffic = round(float(tj["hbm_bytes_per_launch"]), 1)
-                        break
-                except Exception:
-                    pass
-        # issue-side figures of the same kernel from the newest committed PMC profile of this workload (rocprofv3 --pmc passes,
-        # profiles/collect.sh), per frame: VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), kernel cycles =
-        # GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
-        # (r01_v4: 0.32 for k_wf_ext, 0.57 for k_wf_shade, the figures VERDICT r1 quotes); wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES
-        issue = None
-        if traffic is not None:
-            import glob
-            for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_per_kernel.json")), reverse=True):
-                try:
-                    pk = json.load(open(pf)).get(kname, {})
-                    g = lambda c: float(pk[c]["sum_over_one_frame"])
-                    cyc = g("GRBM_GUI_ACTIVE") if "GRBM_GUI_ACTIVE" in pk else None
-                    issue = {"profile": os.path.relpath(os.path.dirname(pf), ROOT),
-                             "lane_utilisation": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4),
-                             "wait_share": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4)}
-                    if cyc:
-                        issue["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * cyc / 8.0), 4)
-                    break
-                except Exception:
-                    continue
-        pipeline_gbps = alg_bytes_launch / (frame_ms * 1e-3) / 1e9
+            traffic, issue, _ = benchline.newest_profile_figures(ROOT, kname)
+        trav = kname == "k_wf_ext"
+        roofline = benchline.roofline_block(
+            kname, k_bytes, k_ms, k_launches, frame_ms, alg_bytes_launch,
+            st_count.box_tests / max(1, st_count.rays), st_count.tri_tests / max(1, st_count.rays),
+            trav_box_tests=st_count.traversal_box_tests if trav else None, trav_tri_tests=st_count.traversal_tri_tests if trav else None,
+            traffic=traffic, issue=issue, note=roof_note)
         result = {
             "metric": f"Mrays/sec (path segments/s), {args.scene} {W}x{H} {spp}spp",
             "value": round(mrays, 3),
@@ -261,36 +268,8 @@ def main():
                        "msamples_per_s": round(total_samples / seconds / 1e6, 3),
                        "wall_clock_s_per_frame": round(seconds / args.steps, 6),
                        "reference_readme_wall_clock_s": 150.0},
-            # achieved / frac: SURVEY 8(d)'s ALGORITHMIC bytes against the HBM peak (the graded definition).  `bound` says what the
-            # kernel is really limited by: when the counters show that HBM moved a fraction of those bytes (the BVH lives in L2),
-            # it is instruction issue and L2 latency, and hbm_measured_* give the true HBM figures.
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": round(k_bytes, 1), "kernel_ms_per_launch": round(k_ms, 5),
-                         "launches_per_frame": k_launches, "kernel_ms_per_frame": round(k_ms * k_launches, 4),
-                         "frame_pipeline_ms": round(frame_ms, 4), "frame_algorithmic_bytes": alg_bytes_launch,
-                         "frame_algorithmic_gbps": round(pipeline_gbps, 2),
-                         "box_tests_per_ray": round(st_count.box_tests / max(1, st_count.rays), 3),
-                         "tri_tests_per_ray": round(st_count.tri_tests / max(1, st_count.rays), 3)},
+            "roofline": roofline,
         }
-        roof = result["roofline"]
-        roof["definition"] = "achieved = algorithmic bytes per launch (32 B per box tested + 36 B per triangle tested, SURVEY 8d) / mean launch time"
-        if kname == "k_wf_ext":   # the culling node really holds 16 B per box (two boxes per 32-byte record, hrt_pack.h)
-            b16 = (16.0 * st_count.traversal_box_tests + 36.0 * st_count.traversal_tri_tests) / k_launches
-            roof["achieved_at_16B_per_box"] = round(b16 / (k_ms * 1e-3) / 1e9, 2)
-            roof["frac_at_16B_per_box"] = round(b16 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
-        if traffic:
-            roof["hbm_measured_gbps"] = round(traffic / (k_ms * 1e-3) / 1e9, 2)
-            roof["hbm_measured_frac"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
-        if issue:
-            roof["issue"] = issue
-        if roof_note is None and traffic and traffic < 0.5 * k_bytes:
-            roof["bound"] = "issue"      # not HBM: see hbm_measured_frac and issue{}
-            roof["bound_of_the_algorithmic_figure"] = "hbm"
-            roof_note = ("the BVH is L2-resident: measured HBM traffic is %.0f %% of the algorithmic bytes, so 'frac' prices L2-served bytes against "
-                         "the HBM peak and can exceed 1; the kernel is bound by instruction issue and by the latency of its divergent node fetches (63 % of a node step is the wait for two 16-byte loads served by L1 / L2), not by HBM (DESIGN.md 4.1)" % (100.0 * traffic / k_bytes))
-        if roof_note:
-            result["roofline"]["note"] = roof_note
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
             from oracle import oracle_py as orc
             cores = host_cores()

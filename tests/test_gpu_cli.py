@@ -190,3 +190,53 @@ def test_bench_one_rank_through_the_nccl_backend(built, tmp_path):
     a, b = np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy")
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert outs[0]["config"]["rays_per_step"] == outs[1]["config"]["rays_per_step"] and outs[1]["n_gpus"] == 1
+
+
+def test_bench_default_workload_prints_the_whole_line(built):
+    """bench.py at its DEFAULT workload (the headline frame: no --width / --height / --spp), one step: rc 0, exactly one JSON line,
+    with roofline (incl. the committed-profile branch: traffic, hbm_measured_frac, issue, l2_frac), cpu_baseline and the CLI's wall
+    clock.  Round 2's driver bench died in exactly the branch that only this workload takes."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["value"] > 1000 and j["dtype"] == "f32"
+    assert "640x640 100spp" in j["config"]["workload"] and j["config"]["samples_per_step"] == 640 * 640 * 100
+    assert j["config"]["cli_wall_clock_s"] and j["config"]["cli_wall_clock_s"] > 0
+    roof = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_measured_frac", "issue", "l2_frac", "kernel_ms_per_launch"):
+        assert k in roof, k
+    assert roof["kernel"] == "k_wf_ext" and roof["traffic"] > 0 and 0 < roof["l2_frac"] < 1 and roof["peak"] == 8000.0
+    assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
+    assert roof["kernel_ms_per_frame"] < j["ms_per_step"]          # the kernel is part of the frame
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s"
+
+
+def test_bench_gpus_2_without_a_launcher(built, tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset), the way the driver starts N = 1: the parent starts
+    its own ranks as a child torch.distributed.run and relays rank 0's ONE line.  (Two ranks share the box's one GPU, so gloo.)"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "1", "--warmup", "0", "--width", "96", "--height", "72", "--spp", "4", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--film-out", str(tmp_path / "one.npy")],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", *common, "--film-out", str(tmp_path / "two.npy")],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, two.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "roofline" in j
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
