@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB_PATH = os.path.join(LIB_DIR, "libhrt_hip.so")
+HIP_LIB_PATH = os.environ.get("HRT_HIP_LIB") or os.path.join(LIB_DIR, "libhrt_hip.so")   # HRT_HIP_LIB: an instrumented build of the
+# same library (-DHRT_DEBUG_BOUNDS, profiling variants; tests/tools), never another implementation
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libhrt_host.so")
 CLI_PATH = os.path.join(_HERE, "bin", "hobbyraytracer")
 
@@ -125,7 +126,8 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 HIP_SYMBOLS = ["hrt_device_count", "hrt_scene_create", "hrt_scene_destroy", "hrt_render_tile", "hrt_render_stripes_device",
                "hrt_render_stripes", "hrt_render_stripes_accumulate_device", "hrt_render_stripes_accumulate", "hrt_stripe_rows", "hrt_stripe_row_index", "hrt_scene_stats", "hrt_resolve_u8",
                "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version",
-               "hrt_multi_create", "hrt_multi_destroy", "hrt_multi_devices", "hrt_multi_uses_rccl", "hrt_multi_render", "hrt_bvh_build_device"]
+               "hrt_multi_create", "hrt_multi_destroy", "hrt_multi_devices", "hrt_multi_uses_rccl", "hrt_multi_render", "hrt_bvh_build_device",
+               "hrt_debug_bounds_violations"]
 HOST_SYMBOLS = ["hrt_host_load_yaml", "hrt_host_free", "hrt_host_flat", "hrt_host_film", "hrt_host_camera", "hrt_host_bvh_depth",
                 "hrt_default_params", "hrt_asset_write_teapot_obj", "hrt_asset_write_bust_obj", "hrt_asset_write_hall_hdr",
                 "hrt_host_write_image", "hrt_host_read_hdr", "hrt_host_read_png", "hrt_host_read_jpeg", "hrt_host_write_hdr", "hrt_host_write_pfm", "hrt_host_read_pfm", "hrt_host_last_error", "hrt_host_set_bvh_builder"]
@@ -477,11 +479,13 @@ class DeviceScene:
 class MultiScene:
     """hrt_multi_*: the flat scene on several devices of this process + the RCCL gather of their film stripes."""
 
-    def __init__(self, flat, devices=(0,), force_rccl=False):
+    def __init__(self, flat, devices=(0,), force_rccl=False, loopback=False):
+        """loopback: the test mode of hrt_multi_create (force_rccl < 0) -- a device may be listed once per logical rank and the
+        gather is one device copy per rank instead of ncclAllGather."""
         flat_ptr = flat if not isinstance(flat, FlatScene) else C.pointer(flat)
         devs = (C.c_int32 * len(devices))(*devices)
         h = _vp()
-        _check(_hip.hrt_multi_create(flat_ptr, len(devices), devs, 1 if force_rccl else 0, C.byref(h)))
+        _check(_hip.hrt_multi_create(flat_ptr, len(devices), devs, -1 if loopback else (1 if force_rccl else 0), C.byref(h)))
         self._h = h
         self._keep = flat
 
@@ -522,6 +526,17 @@ def math_probe(op, a, b=None, device=0):
     bb = _f32(b) if b is not None else None
     _check(_hip.hrt_math_probe(device, op, n, _ptr(a), _ptr(bb) if bb is not None else None, _ptr(out)))
     return out
+
+
+def debug_bounds_violations(device=0):
+    """The 8 violation counters of a -DHRT_DEBUG_BOUNDS build (read and cleared), or None from a normal build."""
+    out = (C.c_int64 * 8)()
+    _hip.hrt_debug_bounds_violations.argtypes = [C.c_int32, C.POINTER(C.c_int64)]
+    st = _hip.hrt_debug_bounds_violations(device, out)
+    if st == HRT_ERR_UNSUPPORTED:
+        return None
+    _check(st)
+    return list(out)
 
 
 def version():

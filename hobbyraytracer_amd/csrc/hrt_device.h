@@ -101,6 +101,30 @@ struct DCounters {
     uint32_t box_tests, tri_tests;
 };
 
+// ---- WorldHit::sub of a MESH hit = mesh-local triangle index in the low 28 bits (hrt_scene_create refuses meshes of 2^28 or more
+// triangles) + the flags HRT_SUB_TIE_UNSETTLED / HRT_SUB_WRAPPERLESS / HRT_SUB_STALE_BACK above it (defined where they are
+// produced, below).  EVERY reader of a triangle index goes through sub_tri: an index that still carries a flag addresses
+// tri_pos / tri_attr 2^28..2^30 records past the mesh (a round-2 ablation build that skipped the settling of
+// HRT_SUB_TIE_UNSETTLED died of exactly that: DESIGN.md 6.1, "the NO_SETTLE fault").
+#define HRT_SUB_TRI_MASK 0x0fffffff
+__device__ inline int sub_tri(int sub) { return sub & HRT_SUB_TRI_MASK; }
+__device__ inline int sub_flags(int sub) { return sub & ~HRT_SUB_TRI_MASK; }
+
+// -DHRT_DEBUG_BOUNDS (tests/tools/debug_bounds.sh): every table index a hit record is built from is checked against its table;
+// a violation is COUNTED (hrt_debug_bounds_violations) and the index replaced by 0, so that the run goes on and ends with a
+// number instead of a GPU memory fault.
+#if defined(HRT_DEBUG_BOUNDS) && defined(__HIPCC__)
+#define HRT_BOUNDS_SLOTS 8      // 0 triangle of a mesh, 1 prim, 2 material, 3 texture, 4 mesh, 5 frontFace source (k_wf_stale), 6 reference-tree node
+static __device__ unsigned long long g_hrt_bounds_violations[HRT_BOUNDS_SLOTS];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HRT_BOUNDS(slot, idx, n) do { if ((unsigned long long)(long long)(idx) >= (unsigned long long)(n)) { atomicAdd(&g_hrt_bounds_violations[slot], 1ull); (idx) = 0; } } while (0)
+#else
+#define HRT_BOUNDS(slot, idx, n) do { } while (0)
+#endif
+#else
+#define HRT_BOUNDS(slot, idx, n) do { } while (0)
+#endif
+
 __device__ inline void set_face_normal(DRec& rec, vec3 rdir, vec3 outward) {  // hittable.h:21-24
     rec.frontFace = dot(rdir, outward) < 0;
     rec.normal = rec.frontFace ? outward : -outward;
@@ -868,6 +892,7 @@ __device__ inline int bvh_traverse(const DScene& sc, int mi /* mesh index */, ve
 
 // triangle.cpp:111-128 for the winning triangle
 __device__ inline void tri_rec(const DScene& sc, const hrt_mesh& mesh, int tri, vec3 o, vec3 d, uint32_t quirks, DRec& rec) {
+    HRT_BOUNDS(0, tri, mesh.tri_count);
     const float4* tpos = sc.tri_pos + 3ull * mesh.tri_first;
     const float4* tattr = sc.tri_attr + 4ull * mesh.tri_first;
     const TriRay tr = tri_ray_setup(o, d, quirks);
@@ -967,7 +992,9 @@ __device__ inline void prims_range_hit(const DScene& sc, int p0, int p1, vec3 o,
 // stale_back: the winner is a mesh hit marked HRT_SUB_WRAPPERLESS and the frontFace it inherits is `false`.
 __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, float t_min_for_ties, DRec& rec,
                                  bool stale_back = false) {
-    const hrt_prim& pr = sc.lprims[wh.prim];
+    int prim_i = wh.prim;
+    HRT_BOUNDS(1, prim_i, sc.n_prims);
+    const hrt_prim& pr = sc.lprims[prim_i];
     vec3 lo = o, ld = d;
     const int n = pr.n_xforms;
     // The wrapper chain, outermost first; d_k = the direction wrapper k handed to its child.  Written as NESTED ifs on
@@ -1006,18 +1033,20 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
     rec.frontFace = true;
     const int kind = pr.kind;
     if (kind == HRT_PRIM_MESH) {
-        int tri = wh.sub & ~(HRT_SUB_WRAPPERLESS | HRT_SUB_STALE_BACK);
-        if (tri & HRT_SUB_TIE_UNSETTLED) {
+        int tri = sub_tri(wh.sub);
+        int mesh_i = pr.mesh;
+        HRT_BOUNDS(4, mesh_i, sc.n_meshes);
+        if (wh.sub & HRT_SUB_TIE_UNSETTLED) {
             // three or more hits within an ulp or two of each other: the reference's own walk decides (from a t_max just beyond
             // them: whatever lay clearly nearer would have won already)
-            const uint32_t* rm = (const uint32_t*)sc.rmesh + 4 * pr.mesh;      // (a per-lane index: plain loads)
+            const uint32_t* rm = (const uint32_t*)sc.rmesh + 4 * mesh_i;      // (a per-lane index: plain loads)
             DCounters none; none.box_tests = 0; none.tri_tests = 0;
             float t_settled;
             const int exact = ref_walk<false>(sc.rnodes + 2ull * rm[0], sc.rtris + 3ull * rm[2], rm[1], lo, ld, tri_ray_setup(lo, ld, quirks), t_min_for_ties,
                                               wh.t + fabsf(wh.t) * 4e-6f, quirks, t_settled, none);
-            tri = exact >= 0 ? exact : (tri & ~HRT_SUB_TIE_UNSETTLED);
+            if (exact >= 0) tri = exact;
         }
-        tri_rec(sc, sc.lmeshes[pr.mesh], tri, lo, ld, quirks, rec);
+        tri_rec(sc, sc.lmeshes[mesh_i], tri, lo, ld, quirks, rec);
         if (stale_back) rec.frontFace = false;      // (only ever set for a wrapper-less mesh under Q-3: nothing below rewrites it)
     }
     else if (kind == HRT_PRIM_SPHERE) sphere_rec(pr.p, lo, ld, wh.t, rec);
@@ -1050,7 +1079,9 @@ __device__ inline void world_rec(const DScene& sc, const WorldHit& wh, vec3 o, v
 // frontFace: the source's record first, for that one flag (ONE world_rec body run twice by those lanes, not two bodies: the
 // registers of k_wf_shade are counted).
 __device__ inline void hit_record(const DScene& sc, const WorldHit& wh, vec3 o, vec3 d, uint32_t quirks, float t_min_for_ties, DRec& rec) {
-    const bool wrapperless = sc.lprims[wh.prim].kind == HRT_PRIM_MESH && (wh.sub & HRT_SUB_WRAPPERLESS);
+    int prim_i = wh.prim;
+    HRT_BOUNDS(1, prim_i, sc.n_prims);
+    const bool wrapperless = sc.lprims[prim_i].kind == HRT_PRIM_MESH && (wh.sub & HRT_SUB_WRAPPERLESS);
     bool stale_back = wrapperless && (wh.sub & HRT_SUB_STALE_BACK);
     const bool inherits = wrapperless && !stale_back && wh.s_prim >= 0;
     WorldHit cur = wh;
@@ -1090,6 +1121,7 @@ __device__ inline vec3 tex_leaf(const DScene& sc, const hrt_texture& t, float u,
 __device__ inline vec3 tex_value(const DScene& sc, int tex, float u, float v, vec3 p) {
     // CheckeredTexture (texture.cpp:17-28) may nest; bounded walk instead of recursion
     for (int depth = 0; depth < 4; ++depth) {
+        HRT_BOUNDS(3, tex, sc.n_texs);
         const hrt_texture& t = sc.ltexs[tex];
         if (t.kind != HRT_TEX_CHECKER) return tex_leaf(sc, t, u, v);
         float sines = gsin_wide(10 * p.x) * gsin_wide(10 * p.y) * gsin_wide(10 * p.z);
@@ -1110,7 +1142,9 @@ __device__ inline float matscalar_value(const DScene& sc, const hrt_matscalar& m
 // Returns false when the path ends (DiffuseLight, absorbed Metal).
 __device__ inline bool material_scatter(const DScene& sc, const DRec& rec, vec3 rin_d, const rng_ctx& ctx, vec3& emitted,
                                         vec3& attenuation, vec3& so, vec3& sd) {
-    const hrt_material& m = sc.lmats[rec.mat];
+    int mat_i = rec.mat;
+    HRT_BOUNDS(2, mat_i, sc.n_mats);
+    const hrt_material& m = sc.lmats[mat_i];
     int kind = m.kind;
     emitted = vec3(0.0f);
     if (kind == HRT_MAT_DIFFUSE_LIGHT) {  // material.h:96-104

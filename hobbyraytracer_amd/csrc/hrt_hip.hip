@@ -192,7 +192,7 @@ __global__ __launch_bounds__(HRT_BLOCK) void k_closest_hit(DScene sc, hrt_params
         DRec rec;
         hit_record(sc, wh, o, d, pr.quirks, t_min, rec);
         h.t = rec.t;
-        h.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? (wh.sub & ~(HRT_SUB_WRAPPERLESS | HRT_SUB_STALE_BACK)) : -1;
+        h.tri = sc.prims[wh.prim].kind == HRT_PRIM_MESH ? sub_tri(wh.sub) : -1;
         h.front_face = rec.frontFace ? 1 : 0;
         h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
         h.normal[0] = rec.normal.x; h.normal[1] = rec.normal.y; h.normal[2] = rec.normal.z;
@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void k_wf_stale(DScene sc, hrt_params pr, int 
             const float4 src = w.S4[pos];
             WorldHit wh; wh.t = src.x; wh.prim = __float_as_int(src.y); wh.sub = __float_as_int(src.z); wh.s_prim = -1; wh.s_sub = -1; wh.s_t = 0.0f;
             if (wh.prim < 0) continue;
+            HRT_BOUNDS(5, wh.prim, sc.n_prims);
             const float4 a = w.S0[par][pos], b = w.S1[par][pos];
             DRec rec;
             world_rec(sc, wh, vec3(a.x, a.y, a.z), vec3(a.w, b.x, b.y), pr.quirks, pr.t_min, rec);
@@ -1735,6 +1736,25 @@ const char* hrt_status_str(hrt_status s) {
     return "unknown";
 }
 const char* hrt_last_error(void) { return g_err.c_str(); }
+
+hrt_status hrt_debug_bounds_violations(int32_t device, int64_t* out8) {
+    HRT_API_TRY
+    if (!out8) return fail(HRT_ERR_INVALID, "NULL argument");
+#ifdef HRT_DEBUG_BOUNDS
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long v[HRT_BOUNDS_SLOTS];
+    HIPCHK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_hrt_bounds_violations), sizeof(v)));
+    const unsigned long long zero[HRT_BOUNDS_SLOTS] = {};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_hrt_bounds_violations), zero, sizeof(zero)));
+    for (int k = 0; k < 8; ++k) out8[k] = k < HRT_BOUNDS_SLOTS ? (int64_t)v[k] : 0;
+    return HRT_OK;
+#else
+    (void)device;
+    return fail(HRT_ERR_UNSUPPORTED, "this library was built without -DHRT_DEBUG_BOUNDS");
+#endif
+    HRT_API_CATCH
+}
 const char* hrt_version(void) { return "hrt-mi355x 0.1 (gfx950)"; }
 
 hrt_status hrt_device_count(int* n) {
@@ -2148,6 +2168,8 @@ struct hrt_multi {
     int W = 0, H = 0, R = 0;
     long long share = 0;
     bool use_rccl = false;
+    bool loopback = false;               // test mode (force_rccl < 0): logical ranks may share a device, the gather is G device copies
+    bool poisoned = false;               // a rank failed inside a render: the ranks' sums no longer describe the same sample range
 };
 
 namespace {
@@ -2195,8 +2217,8 @@ hrt_status fail_nccl(ncclResult_t r, const char* what) { g_err = std::string(wha
 void multi_free_buffers(hrt_multi* m) {
     for (size_t g = 0; g < m->devices.size(); ++g) {
         (void)hipSetDevice(m->devices[g]);
+        if (g < m->d_gather.size() && m->d_gather[g] && (g >= m->d_accum.size() || m->d_gather[g] != m->d_accum[g])) (void)hipFree(m->d_gather[g]);
         if (g < m->d_accum.size() && m->d_accum[g]) (void)hipFree(m->d_accum[g]);
-        if (g < m->d_gather.size() && m->d_gather[g] && (m->use_rccl || g != 0)) (void)hipFree(m->d_gather[g]);
     }
     m->d_accum.clear(); m->d_gather.clear();
     if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
@@ -2217,9 +2239,9 @@ hrt_status multi_reserve(hrt_multi* m, int W, int H, int R) {
         HIPCHK(hipSetDevice(m->devices[g]));
         HIPCHK(hipMalloc((void**)&m->d_accum[g], (size_t)m->share * sizeof(float)));
         HIPCHK(hipMemset(m->d_accum[g], 0, (size_t)m->share * sizeof(float)));
-        if (m->use_rccl) HIPCHK(hipMalloc((void**)&m->d_gather[g], (size_t)m->share * G * sizeof(float)));
+        if (m->use_rccl || (m->loopback && g == 0 && G > 1)) HIPCHK(hipMalloc((void**)&m->d_gather[g], (size_t)m->share * G * sizeof(float)));
     }
-    if (!m->use_rccl) m->d_gather[0] = m->d_accum[0];                  // one device, no communicator: its stripes ARE the gathered buffer
+    if (!m->d_gather[0]) m->d_gather[0] = m->d_accum[0];               // one rank, no communicator: its stripes ARE the gathered buffer
     HIPCHK(hipSetDevice(m->devices[0]));
     HIPCHK(hipMalloc((void**)&m->d_film, (size_t)W * H * 3 * sizeof(float)));
     HIPCHK(hipMalloc((void**)&m->d_mean, (size_t)W * H * 3 * sizeof(float)));
@@ -2249,10 +2271,14 @@ hrt_status hrt_multi_create(const hrt_flat_scene* flat, int32_t n_devices, const
     for (int g = 0; g < n_devices; ++g) {
         const int d = devices ? devices[g] : g;
         if (d < 0 || d >= ndev) { delete m; return fail(HRT_ERR_INVALID, "device index out of range"); }
-        for (int k : m->devices) if (k == d) { delete m; return fail(HRT_ERR_INVALID, "device listed twice"); }
+        if (force_rccl >= 0) for (int k : m->devices) if (k == d) { delete m; return fail(HRT_ERR_INVALID, "device listed twice"); }
         m->devices.push_back(d);
     }
-    m->use_rccl = n_devices > 1 || force_rccl != 0;
+    // force_rccl < 0: LOOPBACK, a test mode for boxes with fewer devices than ranks -- a device may be listed more than once and
+    // the gather is one device-to-device copy per rank instead of ncclAllGather (RCCL refuses two ranks on one device); everything
+    // else (a host thread, a stream and a scene per rank, padded shares, idle ranks, k_unstripe / k_restripe) is the production code
+    m->loopback = force_rccl < 0;
+    m->use_rccl = !m->loopback && (n_devices > 1 || force_rccl != 0);
     m->scenes.assign(n_devices, nullptr); m->streams.assign(n_devices, nullptr);
     for (int g = 0; g < n_devices; ++g) {
         hrt_status st = hrt_scene_create(flat, m->devices[g], &m->scenes[g]);
@@ -2287,6 +2313,11 @@ hrt_status hrt_multi_render(hrt_multi* m, const hrt_camera* cam, const hrt_param
     const int W = pr->width, H = pr->height, W3 = W * 3;
     st = multi_reserve(m, W, H, R);
     if (st != HRT_OK) return st;
+    if (m->poisoned) {
+        if (!resume_sums && !(sample_first == 0 && sample_count > 0))
+            return fail(HRT_ERR_INVALID, "an earlier render of this session failed on one rank after others had added their samples: pass resume_sums or start again at sample 0");
+        m->poisoned = false;
+    }
     const long long n_film = (long long)H * W3;
     auto blocks_for = [&](long long n) { return (int)std::min<long long>((n + 255) / 256, (long long)m->scenes[0]->n_cus * 8); };
 
@@ -2321,11 +2352,21 @@ hrt_status hrt_multi_render(hrt_multi* m, const hrt_camera* cam, const hrt_param
             rst[g] = hrt_render_stripes_accumulate_device(m->scenes[g], cam, pr, R, g, G, m->d_accum[g], sample_first, sample_count, m->streams[g]);
             if (rst[g] != HRT_OK) rerr[g] = g_err;
         };
-        std::vector<std::thread> threads;
-        for (int g = 1; g < G; ++g) threads.emplace_back(work, g);
-        work(0);
-        for (auto& t : threads) t.join();
-        for (int g = 0; g < G; ++g) if (rst[g] != HRT_OK) return fail(rst[g], "device " + std::to_string(m->devices[g]) + ": " + rerr[g]);
+        {
+            struct Joiner {      // an exception (std::thread's constructor can throw) must not destroy joinable threads: std::terminate
+                std::vector<std::thread> threads;
+                ~Joiner() { for (auto& t : threads) if (t.joinable()) t.join(); }
+            } pool;
+            pool.threads.reserve(G);
+            for (int g = 1; g < G; ++g) pool.threads.emplace_back(work, g);
+            work(0);
+        }
+        for (int g = 0; g < G; ++g) if (rst[g] != HRT_OK) {
+            // the other ranks HAVE added this sample range to their sums: the session's sums are inconsistent from here on
+            m->poisoned = true;
+            return fail(rst[g], "device " + std::to_string(m->devices[g]) + " (rank " + std::to_string(g) + "): " + rerr[g] +
+                                " -- the session's sums are now inconsistent across ranks: continue with resume_sums (a checkpoint) or from sample 0");
+        }
     }
     // ---- gather the device-resident stripes: equal (padded) shares, one ncclAllGather per communicator, grouped
     if (m->use_rccl) {
@@ -2336,6 +2377,20 @@ hrt_status hrt_multi_render(hrt_multi* m, const hrt_camera* cam, const hrt_param
             if (r != ncclSuccess) { (void)rccl.GroupEnd(); return fail_nccl(r, "ncclAllGather"); }
         }
         NCCLCHK(rccl.GroupEnd());
+    } else if (m->loopback && G > 1) {
+        // loopback stand-in for the collective: rank g's share -> slot g of the first rank's receive buffer, on rank g's own stream
+        // (ordered behind its render, as the collective would be), and the first rank's stream waits for all of them
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(hipSetDevice(m->devices[g]));
+            HIPCHK(hipMemcpyAsync(m->d_gather[0] + (size_t)g * m->share, m->d_accum[g], (size_t)m->share * sizeof(float), hipMemcpyDeviceToDevice, m->streams[g]));
+            if (g == 0) continue;
+            hipEvent_t ev;
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t e1 = hipEventRecord(ev, m->streams[g]);
+            hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(m->streams[0], ev, 0) : e1;
+            (void)hipEventDestroy(ev);
+            if (e2 != hipSuccess) return fail_hip(e2, "loopback gather: event");
+        }
     }
     // ---- first device: film order, preview mean, tonemap, copies
     HIPCHK(hipSetDevice(m->devices[0]));

@@ -22,6 +22,8 @@
 
 #include <cstdint>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -218,8 +220,16 @@ hrt_status lfail(hrt_status st, const std::string& msg) { hrt_set_last_error(msg
 
 #define LCHK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) return lfail(e_ == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
-                                           uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out) {
+namespace {
+struct DeviceGuard {      // the caller's current device is put back on every way out
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define LLAUNCH(name) do { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return lfail(HRT_ERR_HIP, std::string(name " launch: ") + hipGetErrorString(e_)); } while (0)
+
+hrt_status bvh_build_device_impl(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
+                                 uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out) {
     if (!tri_pos || !nodes_out || !n_nodes_out || !order_out || !depth_out) return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: NULL argument");
     if (max_leaf < 1 || max_leaf > 8) return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: max_leaf must be 1..8");
     if (n_tris <= max_leaf || n_tris >= (1u << 28)) return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: needs max_leaf < n_tris < 2^28");
@@ -228,6 +238,7 @@ extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uin
     int n_dev = 0;
     LCHK(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev) return lfail(HRT_ERR_NO_DEVICE, "hrt_bvh_build_device: no such device");
+    DeviceGuard guard;
     LCHK(hipSetDevice(device));
     const int n = (int)n_tris, n_inner = n - 1;
     DevBufs bufs;
@@ -238,14 +249,21 @@ extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uin
     LCHK(bufs.get(&d_range, (size_t)n_inner)); LCHK(bufs.get(&d_kids, (size_t)n_inner)); LCHK(bufs.get(&d_pin, (size_t)n_inner)); LCHK(bufs.get(&d_pleaf, (size_t)n));
     // real | dense | depth | visits in one allocation each would do; kept apart for clarity
     LCHK(bufs.get(&d_real, (size_t)n_inner)); LCHK(bufs.get(&d_dense, (size_t)n_inner)); LCHK(bufs.get(&d_depth, (size_t)n_inner)); LCHK(bufs.get(&d_visits, (size_t)n_inner));
-    hipStream_t stream = nullptr;
+    struct OwnStream {      // a stream of its own, not the legacy NULL stream (which serialises with every other stream of the process)
+        hipStream_t s = nullptr;
+        ~OwnStream() { if (s) (void)hipStreamDestroy(s); }
+    } own;
+    LCHK(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
+    hipStream_t stream = own.s;
     LCHK(hipMemcpyAsync(d_pos, tri_pos, 9ull * n * sizeof(float), hipMemcpyHostToDevice, stream));
     const uint32_t init_bounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     LCHK(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
     LCHK(hipMemsetAsync(d_visits, 0, (size_t)n_inner * sizeof(uint32_t), stream));
     const unsigned gb = (unsigned)((n + 255) / 256), gi = (unsigned)((n_inner + 255) / 256);
     hipLaunchKernelGGL(k_prep, dim3(gb), dim3(256), 0, stream, d_pos, (uint32_t)n, d_tbox, d_bounds);
+    LLAUNCH("k_prep");
     hipLaunchKernelGGL(k_codes, dim3(gb), dim3(256), 0, stream, d_tbox, (uint32_t)n, d_bounds, d_keys_in, d_vals_in);
+    LLAUNCH("k_codes");
     {
         size_t tmp_bytes = 0;
         LCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in, d_keys, d_vals_in, d_vals, (size_t)n, 0, 63, stream));
@@ -253,7 +271,9 @@ extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uin
         LCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, d_keys_in, d_keys, d_vals_in, d_vals, (size_t)n, 0, 63, stream));
     }
     hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(256), 0, stream, d_keys, n, d_range, d_kids, d_pin, d_pleaf);
+    LLAUNCH("k_hierarchy");
     hipLaunchKernelGGL(k_flag, dim3(gi), dim3(256), 0, stream, d_range, n_inner, max_leaf, d_real);
+    LLAUNCH("k_flag");
     {
         size_t tmp_bytes = 0;
         LCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, d_real, d_dense, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
@@ -261,9 +281,10 @@ extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uin
         LCHK(rocprim::exclusive_scan(tmp, tmp_bytes, d_real, d_dense, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
     }
     hipLaunchKernelGGL(k_refit, dim3(gb), dim3(256), 0, stream, d_tbox, d_vals, n, d_kids, d_pin, d_pleaf, d_real, d_nbox, d_depth, d_visits);
+    LLAUNCH("k_refit");
     LCHK(bufs.get(&d_out, (size_t)n_inner));
     hipLaunchKernelGGL(k_emit, dim3(gi), dim3(256), 0, stream, d_tbox, d_vals, n_inner, d_range, d_kids, d_real, d_dense, d_nbox, max_leaf, d_out);
-    LCHK(hipGetLastError());
+    LLAUNCH("k_emit");
     uint32_t last_real = 0, last_dense = 0, root_depth = 0;
     LCHK(hipMemcpyAsync(&last_real, d_real + (n_inner - 1), 4, hipMemcpyDeviceToHost, stream));
     LCHK(hipMemcpyAsync(&last_dense, d_dense + (n_inner - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -275,4 +296,15 @@ extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uin
     *n_nodes_out = n_nodes;
     *depth_out = (int32_t)root_depth;
     return HRT_OK;
+}
+}  // namespace
+
+// include/hrt.h: "never throws" -- std::string, rocprim and the buffer holder can
+extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
+                                           uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out) {
+    try {
+        return bvh_build_device_impl(device, tri_pos, n_tris, max_leaf, nodes_out, n_nodes_out, order_out, depth_out);
+    } catch (const std::bad_alloc&) { return lfail(HRT_ERR_OOM, "hrt_bvh_build_device: out of host memory"); }
+    catch (const std::exception& e) { return lfail(HRT_ERR_INVALID, std::string("hrt_bvh_build_device: ") + e.what()); }
+    catch (...) { return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: unknown C++ exception"); }
 }

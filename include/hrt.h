@@ -333,7 +333,13 @@ int32_t hrt_stripe_row_index(int32_t height, int32_t rows_per_block, int32_t ran
  * indices, NULL = 0..n-1), the film rows are dealt to them in interleaved blocks (hrt_stripe_rows) and every device keeps
  * the running sums of its rows in its own memory.  With more than one device (or force_rccl != 0) the session owns an RCCL
  * communicator per device (ncclCommInitAll) and hrt_multi_render gathers the device-resident stripes on the first device
- * with one grouped ncclAllGather of equal, padded shares over xGMI; nothing but the finished film crosses PCIe. */
+ * with one grouped ncclAllGather of equal, padded shares over xGMI; nothing but the finished film crosses PCIe.
+ * force_rccl < 0 is LOOPBACK, a test mode for boxes with fewer devices than ranks: a device may be listed once per logical
+ * rank and the gather is one device-to-device copy per rank on that rank's stream instead of ncclAllGather (RCCL refuses two
+ * ranks on one device); one host thread, stream and scene per rank, the padded shares, idle ranks and the film assembly are
+ * the production code.
+ * If a rank fails inside hrt_multi_render the others have already added the sample range to their sums: the session then
+ * refuses to continue until it is given resume_sums (a checkpoint) or started again at sample 0. */
 typedef struct hrt_multi hrt_multi;
 hrt_status hrt_multi_create(const hrt_flat_scene* flat, int32_t n_devices, const int32_t* devices, int32_t force_rccl, hrt_multi** out);
 void hrt_multi_destroy(hrt_multi* m);
@@ -368,6 +374,12 @@ hrt_status hrt_closest_hit(hrt_scene* scene, const hrt_params* params, int64_t n
  * check CPU == GPU bit for bit.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x=in, y=in2), 4 log,
  * 5 philox (in = counter words as float bits; out 4 words per input). */
 hrt_status hrt_math_probe(int device, int32_t op, int64_t n, const float* in, const float* in2, float* out);
+
+/* Debug entry: a library built with -DHRT_DEBUG_BOUNDS checks every table index a hit record is built from (triangle of a mesh,
+ * prim, material, texture, mesh, frontFace source) against its table, counts the violations per kind and carries on with index 0
+ * instead of faulting.  Reads and clears the 8 counters of `device`; HRT_ERR_UNSUPPORTED from a normal build
+ * (tests/tools/debug_bounds.sh runs the GPU suite on such a build). */
+hrt_status hrt_debug_bounds_violations(int32_t device, int64_t* out8);
 
 const char* hrt_status_str(hrt_status s);
 const char* hrt_last_error(void);

@@ -105,6 +105,57 @@ def test_multi_gpu_session_through_rccl_on_one_device(built, assets, scenes_dir)
     dev.close()
 
 
+def test_multi_gpu_session_with_several_ranks_in_loopback(built, assets, scenes_dir):
+    """The threaded G > 1 session of hrt_multi_render on the box's ONE device (hrt_multi_create's loopback mode: logical ranks share
+    the device, the gather is one device copy per rank instead of ncclAllGather; everything else is the production code): one host
+    thread + stream + scene per rank, padded shares with H not a multiple of R x G, k_unstripe with G > 1, idle ranks (48 rows = 6
+    blocks for 8 ranks), and a checkpoint written by G = 3 continued with G = 2 and G = 8 through k_restripe -- films, u8 films and
+    segment counts equal hrt_render_tile's bit for bit.  What this does NOT run: ncclCommInitAll / ncclAllGather with more than one
+    device."""
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    for (W, H, spp, Gs, R) in ((100, 77, 6, (2, 3, 8), 8), (48, 48, 5, (8,), 8), (64, 50, 4, (3, 5), 4)):
+        cam = hs.camera(W, H)
+        p = api.default_params(W, H, spp, stats=True)
+        ref, sref = dev.render_tile(cam, p)
+        ref8 = dev.resolve_u8(ref)
+        for G in Gs:
+            m = api.MultiScene(hs.flat_ptr, (0,) * G, loopback=True)
+            assert not m.uses_rccl
+            img, u8, st = m.render(cam, p, rows_per_block=R)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (W, H, G)
+            assert np.array_equal(u8, ref8) and st.rays == sref.rays and st.samples == W * H * spp
+            # a second frame on the same session (buffers reused, sums restarted at sample 0)
+            img_b, _, _ = m.render(cam, p, rows_per_block=R, want_u8=False)
+            assert np.array_equal(img_b.view(np.uint32), ref.view(np.uint32))
+            m.close()
+    # checkpoint across rank counts: 2 samples with G = 3, the rest with G = 2 and with G = 8 (restripe of a film-order checkpoint)
+    W, H, spp = 100, 77, 6
+    cam = hs.camera(W, H)
+    p = api.default_params(W, H, spp)
+    ref, _ = dev.render_tile(cam, p)
+    two, _ = dev.render_tile(cam, api.default_params(W, H, 2))
+    m3 = api.MultiScene(hs.flat_ptr, (0, 0, 0), loopback=True)
+    sums, prev8, _ = m3.render(cam, p, sample_first=0, sample_count=2)
+    assert np.array_equal(prev8, dev.resolve_u8(two))
+    # ... continued on the same session in two more passes
+    m3.render(cam, p, sample_first=2, sample_count=3, want_u8=False)
+    img3, _, _ = m3.render(cam, p, sample_first=5, sample_count=-1)
+    assert np.array_equal(img3.view(np.uint32), ref.view(np.uint32))
+    m3.close()
+    for G in (2, 8):
+        m = api.MultiScene(hs.flat_ptr, (0,) * G, loopback=True)
+        img, u8, _ = m.render(cam, p, sample_first=2, sample_count=-1, resume_sums=sums)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), G
+        assert np.array_equal(u8, dev.resolve_u8(ref))
+        m.close()
+    # a device listed twice stays an error outside the test mode
+    with pytest.raises(Exception, match="listed twice"):
+        api.MultiScene(hs.flat_ptr, (0, 0))
+    dev.close()
+
+
 def test_cli_rccl_flag_gives_the_same_image(built, assets, scenes_dir, tmp_path):
     """The CLI's --gpus path is the multi-GPU session: `--rccl` sends the one-device film through the RCCL gather too."""
     from hobbyraytracer_amd import api
