@@ -32,7 +32,7 @@ TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_ENV = range(4)
 MAX_XFORMS = 4
 Q1_ROTQ_NORMALIZE, Q2_TRI_NO_TMIN, Q3_TRI_NO_FACE, Q4_SHEAR_FROM_ORIGIN = 1, 2, 4, 8
 QUIRKS_REFERENCE, QUIRKS_FIXED = 0xF, 0x0
-FLAG_STATS, FLAG_MEGAKERNEL, FLAG_TIMING, FLAG_THIN_LENS = 1, 2, 4, 8
+FLAG_STATS, FLAG_MEGAKERNEL, FLAG_TIMING, FLAG_THIN_LENS, FLAG_PROGRESS = 1, 2, 4, 8, 16
 
 
 # ---------------------------------------------------------------- structs (hrt.h)
@@ -127,7 +127,7 @@ HIP_SYMBOLS = ["hrt_device_count", "hrt_scene_create", "hrt_scene_destroy", "hrt
                "hrt_render_stripes", "hrt_render_stripes_accumulate_device", "hrt_render_stripes_accumulate", "hrt_stripe_rows", "hrt_stripe_row_index", "hrt_scene_stats", "hrt_resolve_u8",
                "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version",
                "hrt_multi_create", "hrt_multi_destroy", "hrt_multi_devices", "hrt_multi_uses_rccl", "hrt_multi_render", "hrt_bvh_build_device",
-               "hrt_debug_bounds_violations"]
+               "hrt_debug_bounds_violations", "hrt_scene_progress", "hrt_multi_progress"]
 HOST_SYMBOLS = ["hrt_host_load_yaml", "hrt_host_free", "hrt_host_flat", "hrt_host_film", "hrt_host_camera", "hrt_host_bvh_depth",
                 "hrt_default_params", "hrt_asset_write_teapot_obj", "hrt_asset_write_bust_obj", "hrt_asset_write_hall_hdr",
                 "hrt_host_write_image", "hrt_host_read_hdr", "hrt_host_read_png", "hrt_host_read_jpeg", "hrt_host_write_hdr", "hrt_host_write_pfm", "hrt_host_read_pfm", "hrt_host_last_error", "hrt_host_set_bvh_builder"]
@@ -225,7 +225,7 @@ def _ptr(a, t=_fp):
 
 # ---------------------------------------------------------------- host side
 def default_params(width, height, samples, quirks=QUIRKS_REFERENCE, seed=0, max_depth=50, stats=False, megakernel=False, timing=False,
-                   thin_lens=False):
+                   thin_lens=False, progress=False):
     p = Params()
     _host.hrt_default_params(C.byref(p), width, height, samples)
     p.quirks = quirks
@@ -233,7 +233,7 @@ def default_params(width, height, samples, quirks=QUIRKS_REFERENCE, seed=0, max_
     p.seed_hi = (seed >> 32) & 0xFFFFFFFF
     p.max_depth = max_depth
     p.flags = (FLAG_STATS if stats else 0) | (FLAG_MEGAKERNEL if megakernel else 0) | (FLAG_TIMING if timing else 0) | \
-              (FLAG_THIN_LENS if thin_lens else 0)
+              (FLAG_THIN_LENS if thin_lens else 0) | (FLAG_PROGRESS if progress else 0)
     return p
 
 
@@ -427,6 +427,14 @@ class DeviceScene:
         _check(_hip.hrt_render_tile(self._h, C.byref(cam), C.byref(params), rect, _ptr(out), C.byref(st)))
         return out, st
 
+    def progress(self):
+        """(paths ended, paths of the call) of the render call with FLAG_PROGRESS that is running, or ran last, on this scene
+        (hrt_scene_progress: a plain read of host-mapped memory, callable from another thread while the render runs)."""
+        d, t = C.c_uint64(0), C.c_uint64(0)
+        _hip.hrt_scene_progress.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _check(_hip.hrt_scene_progress(self._h, C.byref(d), C.byref(t)))
+        return d.value, t.value
+
     def render_stripes(self, cam, params, rows_per_block, rank, n_ranks):
         rows = stripe_rows(params.height, rows_per_block, rank, n_ranks)
         out = np.empty((rows, params.width, 3), dtype=np.float32)
@@ -499,6 +507,12 @@ class MultiScene:
             self.close()
         except Exception:
             pass
+
+    def progress(self):
+        d, t = C.c_uint64(0), C.c_uint64(0)
+        _hip.hrt_multi_progress.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _check(_hip.hrt_multi_progress(self._h, C.byref(d), C.byref(t)))
+        return d.value, t.value
 
     @property
     def uses_rccl(self):

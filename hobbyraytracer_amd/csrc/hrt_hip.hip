@@ -1215,6 +1215,21 @@ __global__ __launch_bounds__(256) void k_wf_reduce(const float4* __restrict__ ra
     }
 }
 
+// The progress counter of HRT_FLAG_PROGRESS (main.cpp:95-109): paths of this render call that have ended = `base` (batches
+// already reduced) + the batch's slots - the paths still alive, written to host-mapped memory where the reporter reads it.
+__global__ __launch_bounds__(256) void k_wf_progress(const unsigned* __restrict__ live, unsigned n_tasks, unsigned long long base_plus_slots,
+                                                     volatile unsigned long long* host_ctr) {
+    __shared__ unsigned long long total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (unsigned i = threadIdx.x; i < n_tasks; i += blockDim.x) mine += live[i];
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { *host_ctr = base_plus_slots - total; __threadfence_system(); }
+}
+__global__ void k_set_progress(unsigned long long v, volatile unsigned long long* host_ctr) { *host_ctr = v; __threadfence_system(); }
+
 // ---- multi-GPU film assembly (hrt_multi_render): the gathered stripes of all ranks -> film order, and back
 // gathered: G shares of `share` floats; rank g's share holds its rows_g x W x 3 floats (rows in increasing absolute order).
 __global__ __launch_bounds__(256) void k_unstripe(const float* __restrict__ gathered, float* __restrict__ film, int H, int W3, int R, int G, long long share) {
@@ -1297,6 +1312,12 @@ struct hrt_scene {
     std::vector<hipEvent_t> event_pool;
     double kernel_ms = 0.0, traversal_ms = 0.0;
     uint64_t launches = 0, traversal_launches = 0;
+    // HRT_FLAG_PROGRESS: paths ended so far, in host memory mapped into the device (h_ / d_ are the two views of one word),
+    // and what the host adds to it: paths of finished batches of the running call, and the call's total
+    volatile unsigned long long* h_progress = nullptr;
+    unsigned long long* d_progress = nullptr;
+    unsigned long long progress_base = 0;
+    volatile unsigned long long progress_total = 0;
 };
 
 namespace {
@@ -1559,6 +1580,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     ws.first_mesh = n_mesh > 0 ? sc->mesh_prims.front() : sc->n_prims;
     ws.rest = n_mesh > 0 ? sc->mesh_prims.back() + 1 : sc->n_prims;
     const bool stats = (pr->flags & HRT_FLAG_STATS) != 0, timing = (pr->flags & HRT_FLAG_TIMING) != 0;
+    const bool progress = (pr->flags & HRT_FLAG_PROGRESS) != 0 && sc->d_progress;
     int ext_per_cu_env = 0;                              // experiments: k_wf_ext blocks per CU
     if (const char* e = getenv("HRT_EXT_BLOCKS_PER_CU")) ext_per_cu_env = std::min(10, std::max(1, atoi(e)));
     // from which round on a task's remaining rounds run in one k_wf_tail launch (>= D: never)
@@ -1646,6 +1668,8 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
             w.ref_prod = ref_block(r + 1, 0); w.ref_cons = ref_block(D, 0);
             if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
             else hipLaunchKernelGGL(k_wf_shade<false>, dim3(task_blocks), dim3(256), 0, stream, sc->ds, *pr, map, ws, n_local, s0, r, w, sc->d_counters);
+            if (progress)   // paths ended so far = earlier batches + this batch's slots - the live ones (w.live, as k_wf_shade left it)
+                hipLaunchKernelGGL(k_wf_progress, dim3(1), dim3(256), 0, stream, w.live, w.n_tasks, sc->progress_base + n_slots, sc->d_progress);
         }
         if (tail_round < D) {   // the remaining rounds of every task by the wave that pulls it
             TailMeshes tm{};
@@ -1663,6 +1687,10 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         }
         const int rblocks = (int)std::min<size_t>((n_local + 255) / 256, (size_t)sc->n_cus * 8);
         hipLaunchKernelGGL(k_wf_reduce, dim3(rblocks), dim3(256), 0, stream, w.rad, n_local, c, s0 == 0 ? 1 : 0, s0 + c >= pr->samples ? 1 : 0, pr->samples, d_out, sc->d_counters, w.wave_rays, w.n_wave_rays);
+        if (progress) {
+            sc->progress_base += n_slots;
+            hipLaunchKernelGGL(k_set_progress, dim3(1), dim3(1), 0, stream, sc->progress_base, sc->d_progress);
+        }
         HIPCHK(hipGetLastError());
     }
     return HRT_OK;
@@ -1675,6 +1703,12 @@ hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     if (s_first < 0 || s_count < 1 || s_first + s_count > pr->samples) return fail(HRT_ERR_INVALID, "sample range outside [0, samples)");
     if ((pr->flags & HRT_FLAG_MEGAKERNEL) && (s_first != 0 || s_count != pr->samples))
         return fail(HRT_ERR_UNSUPPORTED, "the megakernel path renders all samples in one launch (no partial sample ranges)");
+    if (pr->flags & HRT_FLAG_PROGRESS) {
+        // (reset in stream order: an earlier asynchronous call's last write may still be on its way)
+        hipLaunchKernelGGL(k_set_progress, dim3(1), dim3(1), 0, stream, 0ull, sc->d_progress);
+        sc->progress_base = 0;
+        sc->progress_total = (unsigned long long)map.rw * (unsigned long long)map.rh * (unsigned long long)s_count;
+    }
     hipEvent_t a, b;
     hrt_status st = get_event(sc, &a);
     if (st != HRT_OK) return st;
@@ -1684,6 +1718,10 @@ hrt_status launch_pathtrace(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     st = (pr->flags & HRT_FLAG_MEGAKERNEL) ? launch_megakernel(sc, cam, pr, map, d_out, stream)
                                            : launch_wavefront(sc, cam, pr, map, d_out, stream, s_first, s_count);
     if (st != HRT_OK) return st;
+    if (pr->flags & HRT_FLAG_PROGRESS) {   // whatever path rendered: everything has ended
+        hipLaunchKernelGGL(k_set_progress, dim3(1), dim3(1), 0, stream, (unsigned long long)sc->progress_total, sc->d_progress);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(b, stream));
     sc->pending.push_back({a, b});
     sc->launches++;
@@ -1776,6 +1814,7 @@ void hrt_scene_destroy(hrt_scene* sc) {
     for (hipEvent_t e : sc->event_pool) (void)hipEventDestroy(e);
     if (sc->wf.base) (void)hipFree(sc->wf.base);
     for (void* p : sc->allocs) (void)hipFree(p);
+    if (sc->h_progress) (void)hipHostFree((void*)sc->h_progress);
     delete sc;
 }
 
@@ -1820,7 +1859,9 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     // repack the BVH into 32-byte culling records and the triangles into 16-byte aligned records (hrt_pack.h)
     std::vector<uint32_t> qn;
     std::vector<float> grids;
-    pack_nodes(f, qn, grids);
+    int node_layout = 0;                                  // experiments: HRT_NODE_LAYOUT=treelet (hrt_pack.h treelet_order)
+    if (const char* e = getenv("HRT_NODE_LAYOUT")) node_layout = strcmp(e, "treelet") == 0 ? 1 : 0;
+    pack_nodes(f, qn, grids, node_layout);
     uint4* d_nodes; float4* d_grids;
     UP(d_nodes, qn.data(), qn.size() * sizeof(uint32_t));
     UP(d_grids, grids.data(), grids.size() * sizeof(float));
@@ -1842,6 +1883,17 @@ hrt_status hrt_scene_create(const hrt_flat_scene* f, int device, hrt_scene** out
     unsigned zw = 0;
     UP(sc->d_work, &zw, sizeof(zw));
 #undef UP
+    {   // the progress word: host memory the device can write and any host thread read without a HIP call (hrt_scene_progress);
+        // made here, not at the first render, so that a reporter thread never sees the pointer change
+        void* h = nullptr;
+        e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+        if (e != hipSuccess) { hrt_scene_destroy(sc); return fail_hip(e, "hipHostMalloc (progress counter)"); }
+        memset(h, 0, 64);
+        void* d = nullptr;
+        e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h); hrt_scene_destroy(sc); return fail_hip(e, "hipHostGetDevicePointer"); }
+        sc->h_progress = (volatile unsigned long long*)h; sc->d_progress = (unsigned long long*)d;
+    }
 
     sc->ds.prims = d_prims; sc->ds.mats = d_mats; sc->ds.texs = d_texs; sc->ds.meshes = d_meshes;
     sc->ds.qnodes = d_nodes; sc->ds.grids = d_grids; sc->ds.tri_pos = d_pos; sc->ds.tri_attr = d_attr; sc->ds.tri_box = d_box;
@@ -2295,6 +2347,24 @@ hrt_status hrt_multi_create(const hrt_flat_scene* flat, int32_t n_devices, const
     *out = m;
     return HRT_OK;
     HRT_API_CATCH
+}
+
+hrt_status hrt_scene_progress(const hrt_scene* sc, uint64_t* done, uint64_t* total) {
+    if (!sc || !done || !total) return fail(HRT_ERR_INVALID, "NULL argument");
+    *done = sc->h_progress ? (uint64_t)*sc->h_progress : 0;      // (plain reads of host memory: no HIP call, any thread)
+    *total = (uint64_t)sc->progress_total;
+    if (*done > *total) *done = *total;
+    return HRT_OK;
+}
+hrt_status hrt_multi_progress(const hrt_multi* m, uint64_t* done, uint64_t* total) {
+    if (!m || !done || !total) return fail(HRT_ERR_INVALID, "NULL argument");
+    uint64_t d = 0, t = 0;
+    for (const hrt_scene* s : m->scenes) {
+        uint64_t a = 0, b = 0;
+        if (s && hrt_scene_progress(s, &a, &b) == HRT_OK) { d += a; t += b; }
+    }
+    *done = d; *total = t;
+    return HRT_OK;
 }
 
 int32_t hrt_multi_devices(const hrt_multi* m) { return m ? (int32_t)m->devices.size() : 0; }

@@ -163,7 +163,46 @@ inline void pack_triangles(const hrt_flat_scene* f, const RefTree& ref, std::vec
 // 13 % of its hits that way: tests/test_gpu_scenes.py::test_deep_bvh...).  A whole cell of slack (1.5e-5 x extent, the
 // size of the reference's own 1e-4 padding for the teapot) covers that with room for ray origins ~50 extents away.
 // Empty children (min > max) keep their harmless never-smaller encoding lo=65535, hi=0.
-inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, std::vector<float>& grids) {
+// Node order inside a mesh.  The builders emit depth-first preorder (child0 of node i is node i + 1), so a walk that keeps
+// turning towards child0 stays in one 128-byte line (4 records) and every turn towards child1 leaves it.  layout == 1 packs
+// TREELETS instead: a line is filled with a subtree chosen greedily by box area (the nodes a random ray is most likely to need
+// next), its leftover frontier nodes start the following lines, largest first.  The root stays node 0; only indices change.
+// perm[old] = new.
+inline void treelet_order(const hrt_bvh_node* nodes, uint32_t n, std::vector<uint32_t>& perm) {
+    perm.assign(n, 0xffffffffu);
+    if (n == 0) return;
+    auto area = [&](uint32_t i) {
+        const hrt_bvh_node& d = nodes[i];
+        float lo[3] = {gmin(d.c0_min_x, d.c1_min_x), gmin(d.c0_min_y, d.c1_min_y), gmin(d.c0_min_z, d.c1_min_z)};
+        float hi[3] = {gmax(d.c0_max_x, d.c1_max_x), gmax(d.c0_max_y, d.c1_max_y), gmax(d.c0_max_z, d.c1_max_z)};
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return (x > 0 && y > 0 && z > 0) ? x * y + y * z + z * x : 0.0f;
+    };
+    uint32_t next = 0;
+    std::vector<uint32_t> roots(1, 0u);          // a stack of treelet roots; the most probable is taken first
+    std::vector<uint32_t> frontier;
+    while (!roots.empty()) {
+        const uint32_t root = roots.back(); roots.pop_back();
+        if (perm[root] != 0xffffffffu) continue;
+        frontier.assign(1, root);
+        int placed = 0;
+        while (placed < 4 && !frontier.empty()) {
+            size_t best = 0;
+            for (size_t k = 1; k < frontier.size(); ++k) if (area(frontier[k]) > area(frontier[best])) best = k;
+            const uint32_t i = frontier[best];
+            frontier.erase(frontier.begin() + (long)best);
+            perm[i] = next++; ++placed;
+            if (nodes[i].child0 >= 0 && (uint32_t)nodes[i].child0 < n) frontier.push_back((uint32_t)nodes[i].child0);
+            if (nodes[i].child1 >= 0 && (uint32_t)nodes[i].child1 < n) frontier.push_back((uint32_t)nodes[i].child1);
+        }
+        // what is left starts new lines: smallest pushed first, so that the largest is on top of the stack
+        std::sort(frontier.begin(), frontier.end(), [&](uint32_t a, uint32_t b) { return area(a) < area(b); });
+        for (uint32_t i : frontier) roots.push_back(i);
+    }
+    for (uint32_t i = 0; i < n; ++i) if (perm[i] == 0xffffffffu) perm[i] = next++;      // (unreachable nodes: validation refuses them anyway)
+}
+
+inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, std::vector<float>& grids, int layout = 0) {
     qnodes.assign((size_t)f->n_nodes * 8, 0u);
     grids.assign((size_t)f->n_meshes * 8, 0.0f);
     for (uint32_t m = 0; m < f->n_meshes; ++m) {
@@ -203,13 +242,16 @@ inline void pack_nodes(const hrt_flat_scene* f, std::vector<uint32_t>& qnodes, s
             if (q < 65535) ++q;
             return (uint32_t)q;
         };
+        std::vector<uint32_t> perm;
+        if (layout == 1) treelet_order(nodes, me.node_count, perm);
         for (uint32_t i = 0; i < me.node_count; ++i) {
             const hrt_bvh_node& n = nodes[i];
-            uint32_t* w = &qnodes[8 * ((size_t)me.node_first + i)];
+            uint32_t* w = &qnodes[8 * ((size_t)me.node_first + (perm.empty() ? i : perm[i]))];
             const float b[2][6] = {{n.c0_min_x, n.c0_min_y, n.c0_min_z, n.c0_max_x, n.c0_max_y, n.c0_max_z},
                                    {n.c1_min_x, n.c1_min_y, n.c1_min_z, n.c1_max_x, n.c1_max_y, n.c1_max_z}};
-            const int32_t ch[2] = {n.child0, n.child1};
+            int32_t ch[2] = {n.child0, n.child1};
             for (int c = 0; c < 2; ++c) {
+                if (!perm.empty() && ch[c] >= 0 && (uint32_t)ch[c] < me.node_count) ch[c] = (int32_t)perm[(uint32_t)ch[c]];
                 for (int a = 0; a < 3; ++a)
                     w[4 * c + a] = b[c][0] > b[c][3] ? 65535u : (q_lo(b[c][a], a) | (q_hi(b[c][3 + a], a) << 16));
                 w[4 * c + 3] = (uint32_t)ch[c];

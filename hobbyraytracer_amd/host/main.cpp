@@ -12,6 +12,7 @@
 //     --dump-linear FILE.pfm (the fp32 linear film, bit for bit, next to the tonemapped image)
 //     --obj-indices reference|rebased (multi-object OBJ files: the reference's un-rebased face indices, mesh.cpp:111-114, or correct ones)
 //     --lens (thin-lens sampling with the scene's `aperture`: camera.h:34's commented-out circularRand(lensRadius); off = the reference)
+//     --no-progress (no reporter thread and no progress counter on the device: main.cpp:97-109), --progress-ms N (its interval, 500)
 //     --rccl (gather the film through an RCCL communicator even on one GPU; with --gpus N > 1 it always is)
 #include <chrono>
 #include <cstdio>
@@ -60,6 +61,8 @@ int main(int argc, char** argv) {
         else if (a == "--assets") assets = next("--assets");
         else if (a == "--out") out = next("--out");
         else if (a == "--stats") opt.stats = true;
+        else if (a == "--no-progress") opt.progress = false;
+        else if (a == "--progress-ms") opt.progress_interval_ms = std::max(1, std::atoi(next("--progress-ms")));
         else if (a == "--rccl") opt.force_rccl = true;
         else if (a == "--lens") opt.thin_lens = true;
         else if (a == "--obj-indices") { std::string v = next("--obj-indices"); setenv("HRT_OBJ_INDICES", v == "rebased" ? "rebased" : "reference", 1); }

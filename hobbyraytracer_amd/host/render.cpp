@@ -12,6 +12,9 @@
 #include <atomic>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -102,7 +105,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     pr.width = f.width; pr.height = f.height; pr.samples = f.samples;
     pr.max_depth = opt.max_depth; pr.t_min = 0.001f; pr.quirks = opt.quirks;
     pr.seed_lo = (uint32_t)opt.seed; pr.seed_hi = (uint32_t)(opt.seed >> 32);
-    pr.flags = (opt.stats ? HRT_FLAG_STATS : 0) | (opt.thin_lens ? HRT_FLAG_THIN_LENS : 0);
+    pr.flags = (opt.stats ? HRT_FLAG_STATS : 0) | (opt.thin_lens ? HRT_FLAG_THIN_LENS : 0) | (opt.progress ? HRT_FLAG_PROGRESS : 0);
 
     // The multi-GPU session: scene on every device, stripes accumulated in device memory, RCCL gather (hrt.h hrt_multi_*).
     hrt_multi* multi = nullptr;
@@ -115,10 +118,41 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
     std::cout << "\rPixels rendered: 0/" << numPixels << std::flush;  // main.cpp:100
     const auto t0 = std::chrono::high_resolution_clock::now();
 
+    // The reporter thread (main.cpp:97-109).  The reference counts finished pixels; here all pixels finish together, so the
+    // figure is the pixel-equivalent of the camera paths that have ended: numPixels x paths ended / all paths, read from the
+    // devices' host-mapped progress counters (hrt_multi_progress: no HIP call) every 500 ms.  It is woken when the render is
+    // over instead of sleeping its interval out (the reference's join can cost its run up to 500 ms).
+    std::atomic<long long> pathsBefore{0};          // paths of the passes already finished
+    std::mutex rm;
+    std::condition_variable rcv;
+    bool reporterStop = false;
+    std::thread reporter;
+    if (opt.progress) {
+        reporter = std::thread([&]() {
+            const double allPaths = (double)numPixels * (double)f.samples;
+            std::unique_lock<std::mutex> lk(rm);
+            while (!reporterStop) {
+                if (rcv.wait_for(lk, std::chrono::milliseconds(opt.progress_interval_ms), [&] { return reporterStop; })) break;
+                uint64_t done = 0, total = 0;
+                if (hrt_multi_progress(multi, &done, &total) != HRT_OK) continue;
+                if (done > total) done = total;
+                long long px = (long long)((double)numPixels * ((double)pathsBefore.load() + (double)done) / allPaths);
+                if (px > numPixels) px = numPixels;
+                std::cout << "\rPixels rendered: " << px << "/" << numPixels << std::flush;
+            }
+        });
+    }
+    auto stopReporter = [&]() {
+        if (!reporter.joinable()) return;
+        { std::lock_guard<std::mutex> g(rm); reporterStop = true; }
+        rcv.notify_all();
+        reporter.join();
+    };
+
     const int R = opt.rows_per_block;
     std::vector<float>& lin = film->linear();     // what the film shows: the preview mean, at the end the final mean
     std::vector<float> sums(lin.size(), 0.0f);     // whole-film accumulation buffer (film order), as gathered on the first device
-    auto cleanup = [&]() { hrt_multi_destroy(multi); };
+    auto cleanup = [&]() { stopReporter(); hrt_multi_destroy(multi); };
 
     int s_done = 0;
     bool have_resume = false;
@@ -133,6 +167,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
             return HRT_ERR_INVALID;
         }
         s_done = ck.next_sample;
+        pathsBefore.store((long long)numPixels * (long long)s_done);
         have_resume = true;
         std::cout << "\rResumed at sample " << s_done << "/" << f.samples << std::endl;
     }
@@ -157,6 +192,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
         total.traversal_box_tests += ps.traversal_box_tests; total.traversal_tri_tests += ps.traversal_tri_tests;
         total.kernel_ms += ps.kernel_ms;
         s_done += n;
+        pathsBefore.store((long long)numPixels * (long long)s_done);
         if (!opt.checkpoint.empty()) {
             Checkpoint ck{f.width, f.height, f.samples, s_done, opt.seed, opt.quirks, opt.max_depth, sceneHash(flat, cam)};
             if (!writeCheckpoint(opt.checkpoint, ck, sums)) { std::cerr << "\ncannot write checkpoint " << opt.checkpoint << std::endl; cleanup(); return HRT_ERR_IO; }
@@ -179,6 +215,7 @@ hrt_status render(int /*nThreads*/, const std::shared_ptr<Texture> background, c
         const float k = static_cast<float>(s_done > 0 && s_done < f.samples ? s_done : 1);
         for (size_t i = 0; i < lin.size(); ++i) lin[i] = sums[i] / k;
     }
+    stopReporter();
     std::cout << "\rPixels rendered: " << numPixels << "/" << numPixels << std::flush << "\n";
     hrt_multi_destroy(multi);
     if (stats) *stats = total;

@@ -19,6 +19,8 @@ struct RenderOptions {
     uint64_t seed = 0;
     int max_depth = 50;                 // MAX_DEPTH (main.cpp:32)
     bool stats = false;                 // count box / triangle tests too
+    bool progress = true;               // the reporter thread of main.cpp:97-109: "Pixels rendered: x/N" every 500 ms (--no-progress)
+    int progress_interval_ms = 500;     // main.cpp:107
     // Progressive rendering: samples are taken in passes of `pass_samples` (0 = all at once);
     // after every pass but the last the film holds the preview (mean of the samples so far) and `on_pass`
     // is called (the CLI rewrites the output image there).  With `checkpoint` set, the accumulation sums and

@@ -233,7 +233,9 @@ enum {
                                   default wavefront pipeline (k_wf_*); results are bit-identical */
     HRT_FLAG_TIMING = 1u << 2, /* wavefront pipeline: also time the traversal kernel's launches with HIP events
                                   (hrt_stats.traversal_ms) */
-    HRT_FLAG_THIN_LENS = 1u << 3 /* sample the lens as camera.h:34's commented-out call would (see hrt_camera); off = the reference */
+    HRT_FLAG_THIN_LENS = 1u << 3, /* sample the lens as camera.h:34's commented-out call would (see hrt_camera); off = the reference */
+    HRT_FLAG_PROGRESS = 1u << 4 /* keep the host-readable progress counter of hrt_scene_progress / hrt_multi_progress up to date
+                                    (the reference's reporter thread, main.cpp:97-109): one tiny launch per round */
 };
 
 typedef struct hrt_rect { int32_t x0, y0, w, h; } hrt_rect;   /* y0 = row index from the TOP (pIdx / W) */
@@ -354,6 +356,14 @@ int32_t hrt_multi_uses_rccl(const hrt_multi* m);
  * with any device count).  Blocking.  `stats`: summed over the devices; the two times are the slowest device's. */
 hrt_status hrt_multi_render(hrt_multi* m, const hrt_camera* cam, const hrt_params* params, int32_t rows_per_block, int32_t sample_first,
                             int32_t sample_count, const float* resume_sums, float* out_sums, uint8_t* out_u8, hrt_stats* stats);
+
+/* The reference's progress counter (main.cpp:95-109: `pixelsCompleted`, printed every 500 ms by a reporter thread) for a path
+ * that finishes its pixels together: *paths_done = camera paths (pixel samples) finished so far in the render call that is
+ * running -- or ran last -- on `scene` with HRT_FLAG_PROGRESS, *paths_total = all paths of that call.  The counter lives in
+ * host-mapped memory the device writes after every round: these calls read it without any HIP call or lock, from any thread,
+ * while the render runs.  hrt_multi_progress sums the session's ranks.  (pixels = width * height * done / total.) */
+hrt_status hrt_scene_progress(const hrt_scene* scene, uint64_t* paths_done, uint64_t* paths_total);
+hrt_status hrt_multi_progress(const hrt_multi* m, uint64_t* paths_done, uint64_t* paths_total);
 
 /* Reads and clears the device-side counters of `scene` (synchronises its device). */
 hrt_status hrt_scene_stats(hrt_scene* scene, hrt_stats* stats);

@@ -291,3 +291,63 @@ def test_bench_gpus_2_without_a_launcher(built, tmp_path):
     assert j["n_gpus"] == 2 and j["value"] > 0 and "roofline" in j
     a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_progress_counter_and_the_reporter_thread(built, assets, scenes_dir, tmp_path):
+    """main.cpp:95-109: `pixelsCompleted` + the reporter thread.  Here: HRT_FLAG_PROGRESS keeps a host-mapped counter of ended
+    camera paths up to date (one tiny launch per round), hrt_scene_progress / hrt_multi_progress read it from another thread while
+    the render runs, and the CLI prints "Pixels rendered: x/N" from it.  The film is the same with and without the flag."""
+    import threading
+    import time
+    from hobbyraytracer_amd import api
+    hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
+    W, H, spp = 256, 256, 64
+    cam = hs.camera(W, H)
+    dev = api.DeviceScene(hs.flat_ptr, 0)
+    assert dev.progress() == (0, 0)
+    ref, _ = dev.render_tile(cam, api.default_params(W, H, spp))
+    seen = []
+    stop = threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            seen.append(dev.progress())
+            time.sleep(0.0005)
+    th = threading.Thread(target=poll)
+    th.start()
+    img, _ = dev.render_tile(cam, api.default_params(W, H, spp, progress=True))
+    stop.set(); th.join()
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    total = W * H * spp
+    assert dev.progress() == (total, total)
+    done = [d for d, t in seen if t == total]
+    assert done == sorted(done) and all(0 <= d <= total for d in done)          # monotonic, bounded
+    assert any(0 < d < total for d in done), "no intermediate value was seen while the render ran"
+    # several batches (a small slot cap): the counter goes on across them and still ends at the total
+    os.environ["HRT_WF_MAX_SLOTS"] = str(W * H * 8)
+    try:
+        dev2 = api.DeviceScene(hs.flat_ptr, 0)
+        img2, _ = dev2.render_tile(cam, api.default_params(W, H, spp, progress=True))
+        assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32)) and dev2.progress() == (total, total)
+        dev2.close()
+    finally:
+        del os.environ["HRT_WF_MAX_SLOTS"]
+    # megakernel path: 0 until the launch is over, then everything
+    img3, _ = dev.render_tile(cam, api.default_params(W, H, 4, progress=True, megakernel=True))
+    assert dev.progress() == (W * H * 4, W * H * 4)
+    # the session sums its ranks (loopback: 3 logical ranks on the one device)
+    m = api.MultiScene(hs.flat_ptr, (0, 0, 0), loopback=True)
+    m.render(cam, api.default_params(W, H, 8, progress=True))
+    assert m.progress() == (W * H * 8, W * H * 8)
+    m.close(); dev.close()
+    # the CLI's reporter: intermediate lines at a 1 ms interval, the reference's first and last lines always
+    for f in ("teapot.obj", "old_hall_4k.hdr"):
+        shutil.copy(os.path.join(assets, f), tmp_path / f)
+    shutil.copy(os.path.join(scenes_dir, "teapot_scene.yaml"), tmp_path / "teapot_scene.yaml")
+    p = subprocess.run([api.CLI_PATH, "--size", "512x512", "--spp", "128", "--progress-ms", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1, p.stderr
+    import re
+    vals = [int(x) for x in re.findall(r"Pixels rendered: (\d+)/262144", p.stdout)]
+    assert vals[0] == 0 and vals[-1] == 262144 and vals == sorted(vals) and len(set(vals)) > 2, vals[:20]
+    q = subprocess.run([api.CLI_PATH, "--size", "64x64", "--spp", "4", "--no-progress"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 1 and re.findall(r"Pixels rendered: (\d+)/4096", q.stdout) == ["0", "4096"]

@@ -483,7 +483,8 @@ def test_full_size_properties(built, assets_full, scenes_dir, scene, W, H, spp, 
 
 
 def test_full_size_bust_hit_records_and_small_film(built, assets_full, scenes_dir, monkeypatch):
-    """The ~100k-triangle bust of config C5 (BVH deeper than 20: the larger LDS stack variants): hitRecord parity of 150 000
+    """The ~100k-triangle bust of config C5 (binned-SAH tree: depth 18, the 20-entry LDS stack; the 24- and 32-entry variants run in
+    test_deep_bvh_uses_the_larger_stack_variants and on this mesh's LBVH in test_device_bvh_builder_*): hitRecord parity of 150 000
     rays, and a small film on every render path, both quirk sets, against the oracle."""
     from hobbyraytracer_amd import api
     from oracle import oracle_py as orc

@@ -105,6 +105,109 @@ def test_quaternion_from_general_euler_angles_against_a_float64_rotation_composi
         assert np.abs(got - wrong @ v).max() > 0.05
 
 
+def test_all_four_wrappers_composed_against_a_float64_affine_map(built, tmp_path):
+    """scene.cpp:337-353 wraps an object as Translate(Scale(RotateQuat(RotateY(obj)))) (rotate_y is this build's additive key, the
+    other three the reference's); rotateQuat.cpp:47-63 takes the ray into the child's frame with conjugate(q) * v and the record
+    back with q * v, rotateY.cpp:46-73, scale.cpp:13-24 and translate.cpp:9-16 likewise.  Composed, the chain is the affine map
+    world = T + S . Rq . Ry(theta) . local with Rq = Rz Ry Rx (glm::quat(euler) = qz qy qx).  Checked here end to end through the
+    oracle's world->hit for a wrapped sphere against that map in float64: hit point, t and normal -- a wrong multiplication order or
+    a transposed rotation in ANY of the four wrappers, or between them, moves the hit point by O(1).  With the reference's quirk
+    Q-1 (rotateQuat.cpp:51 normalises the direction) t comes back in units of |d / scale|, the hit point does not move.
+    (glm is absent: this pins the restatement to the documented conventions, 'parity unpinned' stays.)"""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as o
+    r = np.random.default_rng(2024)
+    worst_p = worst_n = 0.0
+    n_hits = 0
+    for case in range(12):
+        ang = r.uniform(-180, 180, 3)
+        theta = r.uniform(-180, 180)
+        sc = float(r.uniform(0.5, 2.0))                     # uniform: scale.cpp does not transform normals (Q-7)
+        T = r.uniform(-2, 2, 3)
+        c = r.uniform(-0.5, 0.5, 3)
+        rad = float(r.uniform(0.4, 1.0))
+        y = tmp_path / f"w{case}.yaml"
+        y.write_text(f"""
+film:
+    width: 8
+    height: 8
+    samples: 1
+    output: w.png
+camera:
+    position: [0, 0, 9]
+    look_at: [0, 0, 0]
+    up: [0, 1, 0]
+    fov: 40
+    aperture: 0.001
+    focal_distance: 9
+    background: grey
+textures:
+  - name: grey
+    type: solid
+    colour: [0.5, 0.5, 0.5]
+materials:
+  - name: m
+    type: lambertian
+    albedo: [0.5, 0.5, 0.5]
+objects:
+  - type: sphere
+    center: [{c[0]:.9g}, {c[1]:.9g}, {c[2]:.9g}]
+    radius: {rad:.9g}
+    material: m
+    transform:
+        rotate_y: {theta:.9g}
+        rotate: [{ang[0]:.9g}, {ang[1]:.9g}, {ang[2]:.9g}]
+        scale: [{sc:.9g}, {sc:.9g}, {sc:.9g}]
+        translate: [{T[0]:.9g}, {T[1]:.9g}, {T[2]:.9g}]
+""")
+        hs = api.HostScene(str(y), str(tmp_path))
+        assert hs.flat.prims[0].n_xforms == 4
+        # what the loader parsed (fp32) is what the float64 model uses
+        f32 = lambda x: np.float32(x).astype(np.float64)
+        ex, ey, ez = np.radians(f32(ang)); th = np.radians(f32(theta))
+        Rx = np.array([[1, 0, 0], [0, np.cos(ex), -np.sin(ex)], [0, np.sin(ex), np.cos(ex)]])
+        Ry = np.array([[np.cos(ey), 0, np.sin(ey)], [0, 1, 0], [-np.sin(ey), 0, np.cos(ey)]])
+        Rz = np.array([[np.cos(ez), -np.sin(ez), 0], [np.sin(ez), np.cos(ez), 0], [0, 0, 1]])
+        Rt = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        M = f32(sc) * (Rz @ Ry @ Rx @ Rt)
+        Minv = np.linalg.inv(M)
+        n_rays = 400
+        org = r.uniform(-6, 6, (n_rays, 3)).astype(np.float32)
+        tgt = (f32(T) + M @ f32(c))[None, :] + r.normal(size=(n_rays, 3)) * 0.6 * rad * sc
+        dirs = ((tgt - org) * r.uniform(0.3, 3.0, (n_rays, 1))).astype(np.float32)      # un-normalised directions, as the path tracer's
+        for quirks in (api.QUIRKS_FIXED, api.QUIRKS_REFERENCE):
+            hits = o.World(hs.flat_ptr).closest_hit(api.default_params(8, 8, 1, quirks=quirks), org, dirs)
+            for i in range(n_rays):
+                oo, dd = org[i].astype(np.float64), dirs[i].astype(np.float64)
+                lo, ld = Minv @ (oo - f32(T)), Minv @ dd
+                oc = lo - f32(c)
+                a, hb, cc = ld @ ld, oc @ ld, oc @ oc - f32(rad) ** 2
+                disc = hb * hb - a * cc
+                if disc < 1e-3 * a * f32(rad) ** 2:            # grazing: fp32 and fp64 may disagree on hit / miss
+                    continue
+                t = (-hb - np.sqrt(disc)) / a
+                if t < 0.01:
+                    t = (-hb + np.sqrt(disc)) / a
+                    if t < 0.01:
+                        continue
+                assert hits["prim"][i] == 0, (case, i)
+                n_hits += 1
+                p_world = oo + t * dd
+                worst_p = max(worst_p, np.abs(hits["p"][i] - p_world).max() / max(1.0, np.abs(p_world).max()))
+                t_want = t * (np.linalg.norm(dd / f32(sc)) if quirks == api.QUIRKS_REFERENCE else 1.0)
+                assert abs(hits["t"][i] - t_want) < 2e-4 * max(1.0, abs(t_want)), (case, i, quirks)
+                n_local = (lo + t * ld - f32(c)) / f32(rad)
+                n_world = (Rz @ Ry @ Rx @ Rt) @ n_local
+                if n_world @ dd > 0:
+                    n_world = -n_world
+                worst_n = max(worst_n, np.abs(hits["normal"][i] - n_world).max())
+    assert n_hits > 3000
+    # fp32 through four wrappers and sphere.cpp's discriminant (half_b^2 - a c cancels for oblique rays): 1e-4 was seen;
+    # any slip of order or direction is O(0.1 .. 1)
+    assert worst_p < 5e-4, worst_p
+    assert worst_n < 5e-3, worst_n
+
+
 def test_reflect_refract_normalize_against_float64(orc):
     """glm::reflect (material.h:168,224), glm::refract (material.h:225: Snell's law), glm::normalize as restated in hrt_glm.h."""
     r = np.random.default_rng(12)
