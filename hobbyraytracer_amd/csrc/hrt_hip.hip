@@ -1565,6 +1565,9 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     size_t cap = wf_max_slots(sc);
     const int s_end = s_first + s_count;
     int chunk = (int)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local));
+    // equal batches: every batch pays the latency of its ~100 launches whatever its size, so the largest possible batches plus a
+    // small remainder (C4 on one GPU: 453 + 59 samples) cost what two of 256 do, and hold 77 % more memory
+    chunk = (s_count + (s_count + chunk - 1) / chunk - 1) / ((s_count + chunk - 1) / chunk);
     hrt_status st;
     for (;;) {   // the memory estimate can be stale (other processes on the device): halve the batch on OOM
         const size_t slots = (size_t)n_local * chunk;
@@ -1589,7 +1592,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     // round 24 wins 4 % (18.5 -> 17.8 ms), on the 1/8 share rounds 2..8 win 11 % (10.9 -> 9.7 ms; 10.1 at round 20).
     // Tiny batches (previews: <= 512 Ki slots) are nothing but launch and wait: the tail from round 1 renders 64x64x4 in
     // 2.2 instead of 2.9 ms.
-    const size_t batch_slots = (size_t)n_local * (size_t)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local));
+    const size_t batch_slots = (size_t)n_local * (size_t)chunk;
     int tail_round = batch_slots <= ((size_t)512 << 10) ? 1 : (batch_slots <= ((size_t)6 << 20) ? 8 : (batch_slots <= ((size_t)12 << 20) ? 24 : D));
     if (const char* e = getenv("HRT_WF_TAIL_ROUND")) tail_round = std::max(1, atoi(e));
     if (n_mesh > HRT_TAIL_MAX_MESHES) tail_round = D;

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <limits>
 
 #include "../csrc/hrt_rng.h"
@@ -268,7 +269,7 @@ BVHNode::BVHNode(TriangleSoup& soup) {
         uint32_t nNodes = 0; int32_t dDepth = 0;
         const hrt_status st = g_deviceBuild(g_deviceBuildDevice, soup.pos.data(), (uint32_t)n, (uint32_t)sb.maxLeaf, dn.data(), &nNodes, order.data(), &dDepth);
         if (st != HRT_OK) throw FlattenError(st, "the device BVH builder failed (hrt_last_error() of libhrt_hip.so has the reason)");
-        if (dDepth > 31 || nNodes == 0) throw FlattenError(HRT_ERR_UNSUPPORTED, "the LBVH of this mesh is deeper than the traversal stack (31 levels): use the SAH builder");
+        if (dDepth <= 31 && nNodes != 0) {
         dn.resize(nNodes);
         TriangleSoup re;
         re.pos.resize(9 * n); re.nrm.resize(9 * n); re.uv.resize(6 * n);
@@ -284,6 +285,11 @@ BVHNode::BVHNode(TriangleSoup& soup) {
         leafBoxes = referenceLeafBoxes(soup, refOrder);
         depth = dDepth;
         return;
+        }
+        // a tree deeper than the traversal's stack (31 levels: clustered geometry inside a huge bound can do that to a Morton
+        // tree) is not truncated and not a reason to fail the load: this mesh gets the host's SAH tree, whose depth is bounded
+        std::cerr << "note: the GPU-built BVH of a mesh of " << n << " triangles is " << dDepth << " levels deep (the traversal stack holds 31): "
+                     "building this mesh's tree with the host SAH builder instead" << std::endl;
     }
     if (const char* e = std::getenv("HRT_BVH_TRI_COST")) sb.triCost = (float)std::atof(e);
     sb.refs.resize(n);

@@ -1,4 +1,4 @@
-"""usage (GPU box, repo root): python3 tests/tools/bvh_builders.py -- the host's binned-SAH builder against hrt_bvh_build_device (LBVH on
+"""usage (GPU box, repo root): python3 tests/tools/bvh_builders.py -- the host's binned-SAH builder against hrt_bvh_build_device / hrt_bvh_build_ploc (LBVH / PLOC on
 the GPU, csrc/hrt_lbvh.hip): scene load time (parse + import + build + flatten), the device build alone, tree size and depth, and what the
 tree costs a render (headline teapot frame, bust scene at 1024x1024x16; wavefront pipeline, reference quirks)."""
 import os, sys, tempfile, time
@@ -8,16 +8,17 @@ from hobbyraytracer_amd import api
 d = tempfile.mkdtemp()
 api.write_teapot_obj(d + "/teapot.obj", 1.0); api.write_bust_obj(d + "/marble_bust_01.obj", 1.0); api.write_hall_hdr(d + "/old_hall_4k.hdr", 512, 256)
 for scene, W, H, spp in (("teapot_scene.yaml", 640, 640, 100), ("bust_scene.yaml", 1024, 1024, 16)):
-    for builder in ("sah", "lbvh"):
-        api.use_device_bvh_builder(builder == "lbvh")
+    for builder in ("sah", "lbvh", "ploc"):
+        api.use_device_bvh_builder(builder != "sah", algo=builder if builder != "sah" else "lbvh")
         try:
             api.HostScene("tests/golden/scenes/" + scene, d)        # warm (file cache, device context)
             t0 = time.time(); hs = api.HostScene("tests/golden/scenes/" + scene, d); t_load = time.time() - t0
         finally:
             api.use_device_bvh_builder(False)
         pos = np.asarray(hs.mesh_arrays(0)[0], dtype=np.float32).reshape(-1, 9)
-        api.bvh_build_device(pos, 2)                                # (the first call of a process loads the code object)
-        t0 = time.time(); api.bvh_build_device(pos, 2); t_dev = time.time() - t0
+        algo = builder if builder != "sah" else "lbvh"
+        api.bvh_build_device(pos, 2, algo=algo)                     # (the first call of a process loads the code object)
+        t0 = time.time(); api.bvh_build_device(pos, 2, algo=algo); t_dev = time.time() - t0
         dev = api.DeviceScene(hs.flat_ptr, 0)
         cam = hs.camera(W, H)
         p = api.default_params(W, H, spp, stats=True)

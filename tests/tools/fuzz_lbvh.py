@@ -1,4 +1,4 @@
-"""usage (GPU box, repo root): python3 tests/tools/fuzz_lbvh.py N [seed] -- random triangle soups through hrt_bvh_build_device
+"""usage (GPU box, repo root): python3 tests/tools/fuzz_lbvh.py N [seed] [lbvh|ploc] -- random triangle soups through hrt_bvh_build_device / hrt_bvh_build_ploc
 (csrc/hrt_lbvh.hip): sizes 3..20000, coordinates from 1e-6 to 1e30 wide, clustered / coincident / degenerate triangles, signed zeros.
 Every tree is walked by tests/test_gpu_scenes.py _lbvh_check (permutation, leaf sizes, child boxes bit for bit, depth); trees deeper than
 the traversal stack are counted, not failed."""
@@ -8,6 +8,7 @@ import numpy as np
 from hobbyraytracer_amd import api
 from tests.test_gpu_scenes import _lbvh_check
 N = int(sys.argv[1]); seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+algo = sys.argv[3] if len(sys.argv) > 3 else "lbvh"
 r = np.random.default_rng(seed)
 bad = deep = 0
 for it in range(N):
@@ -27,7 +28,7 @@ for it in range(N):
     ml = int(r.choice([1, 2, 2, 4, 8]))
     if len(tri) <= ml: continue
     try:
-        nodes, order, depth = api.bvh_build_device(tri, ml)
+        nodes, order, depth = api.bvh_build_device(tri, ml, algo=algo)
         _lbvh_check(tri, nodes, order, depth, ml)
         deep += depth > 31
     except Exception as e:
