@@ -18,11 +18,12 @@ HOST_HDR := $(wildcard $(PKG)/host/*.h) $(wildcard $(PKG)/csrc/*.h) $(wildcard i
 
 all: $(PKG)/lib/libhrt_hip.so $(PKG)/lib/libhrt_host.so $(PKG)/bin/hobbyraytracer oracle/liboracle.so
 
-$(PKG)/lib/libhrt_hip.so: $(PKG)/csrc/hrt_hip.hip $(PKG)/csrc/hrt_lbvh.hip $(HOST_HDR)
+$(PKG)/lib/libhrt_hip.so: $(PKG)/csrc/hrt_hip.hip $(PKG)/csrc/hrt_lbvh.hip $(PKG)/csrc/hrt_sahbvh.hip $(HOST_HDR)
 	@mkdir -p $(PKG)/lib build
 	$(HIPCC) $(HIPFLAGS) -c -o build/hrt_hip.o $(PKG)/csrc/hrt_hip.hip
 	$(HIPCC) $(HIPFLAGS) -c -o build/hrt_lbvh.o $(PKG)/csrc/hrt_lbvh.hip
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ build/hrt_hip.o build/hrt_lbvh.o -ldl
+	$(HIPCC) $(HIPFLAGS) -c -o build/hrt_sahbvh.o $(PKG)/csrc/hrt_sahbvh.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ build/hrt_hip.o build/hrt_lbvh.o build/hrt_sahbvh.o -ldl
 
 $(PKG)/lib/libhrt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(PKG)/lib

@@ -126,7 +126,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 HIP_SYMBOLS = ["hrt_device_count", "hrt_scene_create", "hrt_scene_destroy", "hrt_render_tile", "hrt_render_stripes_device",
                "hrt_render_stripes", "hrt_render_stripes_accumulate_device", "hrt_render_stripes_accumulate", "hrt_stripe_rows", "hrt_stripe_row_index", "hrt_scene_stats", "hrt_resolve_u8",
                "hrt_resolve_u8_device", "hrt_closest_hit", "hrt_math_probe", "hrt_status_str", "hrt_last_error", "hrt_version",
-               "hrt_multi_create", "hrt_multi_destroy", "hrt_multi_devices", "hrt_multi_uses_rccl", "hrt_multi_render", "hrt_bvh_build_device", "hrt_bvh_build_ploc",
+               "hrt_multi_create", "hrt_multi_destroy", "hrt_multi_devices", "hrt_multi_uses_rccl", "hrt_multi_render", "hrt_bvh_build_device", "hrt_bvh_build_sah",
                "hrt_debug_bounds_violations", "hrt_scene_progress", "hrt_multi_progress"]
 HOST_SYMBOLS = ["hrt_host_load_yaml", "hrt_host_free", "hrt_host_flat", "hrt_host_film", "hrt_host_camera", "hrt_host_bvh_depth",
                 "hrt_default_params", "hrt_asset_write_teapot_obj", "hrt_asset_write_bust_obj", "hrt_asset_write_hall_hdr",
@@ -361,11 +361,11 @@ def device_count():
 
 def use_device_bvh_builder(enable=True, device=0, algo="lbvh"):
     """hrt_host_set_bvh_builder: scenes loaded from now on get their meshes' culling trees from the GPU -- hrt_bvh_build_device
-    (algo "lbvh": a Morton-ordered LBVH, fastest) or hrt_bvh_build_ploc ("ploc": the host SAH builder's quality) -- instead of
-    the host's binned-SAH builder."""
+    (algo "lbvh": a Morton-ordered LBVH, fastest) or hrt_bvh_build_sah ("sah": the host builder's own binned-SAH tree, built on
+    the device) -- instead of the host's builder."""
     _host.hrt_host_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
     _host.hrt_host_set_bvh_builder.restype = None
-    fn = {"lbvh": _hip.hrt_bvh_build_device, "ploc": _hip.hrt_bvh_build_ploc}[algo]
+    fn = {"lbvh": _hip.hrt_bvh_build_device, "sah": _hip.hrt_bvh_build_sah}[algo]
     _host.hrt_host_set_bvh_builder(C.cast(fn, C.c_void_p) if enable else None, device)
 
 
@@ -376,7 +376,7 @@ def bvh_build_device(tri_pos, max_leaf=2, device=0, algo="lbvh"):
     nodes = np.zeros((max(n - 1, 1), 16), dtype=np.uint32)
     order = np.zeros(n, dtype=np.uint32)
     n_nodes, depth = C.c_uint32(), C.c_int32()
-    f = {"lbvh": _hip.hrt_bvh_build_device, "ploc": _hip.hrt_bvh_build_ploc}[algo]
+    f = {"lbvh": _hip.hrt_bvh_build_device, "sah": _hip.hrt_bvh_build_sah}[algo]
     f.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     f.restype = C.c_int
     _check(f(device, pos.ctypes.data, n, max_leaf, nodes.ctypes.data, C.addressof(n_nodes), order.ctypes.data, C.addressof(depth)))

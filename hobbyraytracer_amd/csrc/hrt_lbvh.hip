@@ -18,19 +18,6 @@
 //                  node = union of the padded triangle boxes below it; depth of the tree as the traversal's stack sees it
 //   7. k_emit      hrt_bvh_node records: child boxes widened by the same rounding guard host/bvh_build.cpp refit() applies
 //                  (the kernel's fma slab test must never be tighter than a division-based test of the same box)
-//
-// hrt_bvh_build_ploc: the same job with the quality of the host's binned-SAH tree (round 3).  Steps 1-3 as above, then
-// PLOC (Meister & Bittner 2018, "Parallel Locally-Ordered Clustering"): the Morton order is only used to find CANDIDATES --
-// every cluster looks at its 2 x HRT_PLOC_RADIUS neighbours in the array for the one whose union with it has the smallest
-// area, mutual nearest neighbours merge into a new node, the array is compacted, and again until one cluster is left
-// (~0.6 x per pass: ~25 passes for 100 k triangles).  Bottom-up agglomeration by surface area is what SAH builders
-// approximate top-down; the tree comes out within a few per cent of the binned-SAH tree's box tests per ray.
-//   4'. k_ploc_nn    nearest neighbour by union area inside the window (boxes staged in LDS); ties are ranked by a key that is
-//                    symmetric in the pair, so the closest pair of the whole array is always mutual and every pass makes progress
-//   5'. k_ploc_flag + rocprim::exclusive_scan of (kept, merged) pairs + k_ploc_merge: new nodes numbered in creation order
-//   6'. k_ploc_ranges: leaf order = depth-first order of the finished tree (each triangle adds up the sizes of the left
-//                    siblings on its way to the root); nodes of <= max_leaf triangles become leaves
-//   7'. k_ploc_emit  hrt_bvh_node records, root = 0, same rounding guard as above
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -216,147 +203,6 @@ __global__ __launch_bounds__(256) void k_emit(const Box* __restrict__ tbox, cons
     out[dense[i]] = nd;
 }
 
-// ---------------------------------------------------------------- PLOC
-#define HRT_PLOC_RADIUS 16
-__device__ inline float half_area_union(const Box& a, const Box& b) {
-    const float x = fmaxf(a.mx[0], b.mx[0]) - fminf(a.mn[0], b.mn[0]), y = fmaxf(a.mx[1], b.mx[1]) - fminf(a.mn[1], b.mn[1]),
-                z = fmaxf(a.mx[2], b.mx[2]) - fminf(a.mn[2], b.mn[2]);
-    const float h = x * y + y * z + z * x;
-    return h == h ? h : __builtin_huge_valf();             // 0 x inf (a flat box as wide as fp32 allows): treated as huge
-}
-// cluster ids: a triangle at sorted position p is p | 0x80000000, an inner node its creation index
-__global__ __launch_bounds__(256) void k_ploc_init(const Box* __restrict__ tbox, const uint32_t* __restrict__ vals, uint32_t n, uint32_t* __restrict__ cid, Box* __restrict__ cbox) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    cid[i] = i | 0x80000000u; cbox[i] = tbox[vals[i]];
-}
-__global__ __launch_bounds__(256) void k_ploc_nn(const Box* __restrict__ cbox, const uint32_t* __restrict__ m_ptr, uint32_t* __restrict__ nn) {
-    __shared__ Box s_box[256 + 2 * HRT_PLOC_RADIUS];
-    const uint32_t m = *m_ptr;
-    const int base = (int)(blockIdx.x * 256u) - HRT_PLOC_RADIUS;
-    if (blockIdx.x * 256u >= m) return;
-    for (int k = threadIdx.x; k < 256 + 2 * HRT_PLOC_RADIUS; k += 256) {
-        const int g = base + k;
-        if (g >= 0 && g < (int)m) s_box[k] = cbox[g];
-    }
-    __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m) return;
-    const Box mine = s_box[threadIdx.x + HRT_PLOC_RADIUS];
-    // Equal areas (copies of a triangle, boxes as wide as fp32 allows: everything is +inf) are ranked by a key that is SYMMETRIC in
-    // the pair -- "the two are array neighbours 2k, 2k + 1" first, then (lower index, higher index) -- so that "nearest" is a
-    // total order on pairs: the best pair of the whole array is then mutual (every pass merges something), and an array of equal
-    // boxes pairs up completely (it halves per pass instead of losing one pair per pass).
-    float best = __builtin_huge_valf();
-    unsigned long long best_key = ~0ull;
-    uint32_t best_j = 0xffffffffu;
-    for (int k = 0; k <= 2 * HRT_PLOC_RADIUS; ++k) {
-        const int j = (int)i - HRT_PLOC_RADIUS + k;
-        if (j < 0 || j >= (int)m || j == (int)i) continue;
-        const float a = half_area_union(mine, s_box[threadIdx.x + k]);
-        const uint32_t lo = (uint32_t)j < i ? (uint32_t)j : i, hi = (uint32_t)j < i ? i : (uint32_t)j;
-        const unsigned long long key = (((i ^ (uint32_t)j) == 1u) ? 0ull : (1ull << 63)) | ((unsigned long long)lo << 31) | (unsigned long long)hi;
-        if (a < best || (a == best && key < best_key)) { best = a; best_key = key; best_j = (uint32_t)j; }
-    }
-    nn[i] = best_j;
-}
-// flags for the scan: low word = the cluster stays in the array (it is not the upper half of a merging pair), high word = it is the
-// lower half of a merging pair (a new node is made at its place)
-__global__ __launch_bounds__(256) void k_ploc_flag(const uint32_t* __restrict__ nn, const uint32_t* __restrict__ m_ptr, unsigned long long* __restrict__ flags) {
-    const uint32_t m = *m_ptr;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint32_t j = nn[i];
-    const bool mutual = j != 0xffffffffu && nn[j] == i;
-    flags[i] = (mutual && j < i ? 0ull : 1ull) | (mutual && i < j ? (1ull << 32) : 0ull);
-}
-struct PlocTree {      // inner nodes in creation order
-    uint2* kids; Box* nbox; uint32_t* cnt; uint32_t* depth; uint32_t* parent;      // parent of an inner node
-    uint32_t* leaf_parent;                                                          // parent of the triangle at a sorted position
-};
-__global__ __launch_bounds__(256) void k_ploc_merge(const uint32_t* __restrict__ nn, const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ scan,
-                                                    const uint32_t* __restrict__ cid_in, const Box* __restrict__ cbox_in, uint32_t* __restrict__ cid_out,
-                                                    Box* __restrict__ cbox_out, PlocTree t, uint32_t max_leaf, uint32_t* __restrict__ m_ptr, uint32_t* __restrict__ created_ptr,
-                                                    uint32_t* __restrict__ m_next, uint32_t* __restrict__ created_next) {
-    const uint32_t m = *m_ptr, created = *created_ptr;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const unsigned long long f = flags[i], sc = scan[i];
-    const uint32_t pos = (uint32_t)(sc & 0xffffffffu);
-    if (i == m - 1) {      // the totals of this pass, for the next one (ping-pong words: nobody reads what is written here in this pass)
-        *m_next = pos + (uint32_t)(f & 1ull);
-        *created_next = created + (uint32_t)(sc >> 32) + (uint32_t)(f >> 32);
-    }
-    if (!(f & 1ull)) return;                                // the upper half of a pair: its partner writes the node
-    if (f >> 32) {
-        const uint32_t j = nn[i];
-        const uint32_t node = created + (uint32_t)(sc >> 32);
-        const uint32_t a = cid_in[i], b = cid_in[j];
-        Box u = cbox_in[i];
-        const Box o = cbox_in[j];
-        for (int k = 0; k < 3; ++k) { u.mn[k] = fminf(u.mn[k], o.mn[k]); u.mx[k] = fmaxf(u.mx[k], o.mx[k]); }
-        uint32_t cnt = 0, dep = 0;
-        for (int c = 0; c < 2; ++c) {
-            const uint32_t kid = c == 0 ? a : b;
-            if (kid & 0x80000000u) { cnt += 1; t.leaf_parent[kid & 0x7fffffffu] = node; }
-            else { cnt += t.cnt[kid]; dep = t.depth[kid] > dep ? t.depth[kid] : dep; t.parent[kid] = node; }
-        }
-        t.kids[node] = make_uint2(a, b); t.nbox[node] = u; t.cnt[node] = cnt;
-        t.depth[node] = cnt > max_leaf ? dep + 1u : 0u;    // levels of nodes that stay inner nodes (the traversal's stack need)
-        t.parent[node] = 0xffffffffu;
-        cid_out[pos] = node; cbox_out[pos] = u;
-    } else {
-        cid_out[pos] = cid_in[i]; cbox_out[pos] = cbox_in[i];
-    }
-}
-// position of a subtree's first triangle in the depth-first order = sum of the sizes of the left siblings on the way up
-__device__ inline uint32_t ploc_start(const PlocTree& t, uint32_t me, uint32_t parent) {
-    uint32_t off = 0;
-    while (parent != 0xffffffffu) {
-        const uint2 k = t.kids[parent];
-        if (k.y == me) off += (k.x & 0x80000000u) ? 1u : t.cnt[k.x];
-        me = parent; parent = t.parent[parent];
-    }
-    return off;
-}
-__global__ __launch_bounds__(256) void k_ploc_ranges(PlocTree t, const uint32_t* __restrict__ vals, uint32_t n, uint32_t max_leaf, uint32_t* __restrict__ leaf_pos,
-                                                     uint32_t* __restrict__ order, uint32_t* __restrict__ start, uint32_t* __restrict__ real_rev) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const uint32_t p = ploc_start(t, i | 0x80000000u, t.leaf_parent[i]);
-        leaf_pos[i] = p; order[p] = vals[i];
-    }
-    if (i < n - 1) {
-        start[i] = ploc_start(t, i, t.parent[i]);
-        real_rev[n - 2 - i] = t.cnt[i] > max_leaf ? 1u : 0u;   // scanned in REVERSE creation order: the root (made last) becomes node 0
-    }
-}
-__global__ __launch_bounds__(256) void k_ploc_emit(PlocTree t, const Box* __restrict__ tbox, const uint32_t* __restrict__ vals, uint32_t n, uint32_t max_leaf,
-                                                   const uint32_t* __restrict__ leaf_pos, const uint32_t* __restrict__ start, const uint32_t* __restrict__ real_rev,
-                                                   const uint32_t* __restrict__ dense_rev, hrt_bvh_node* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || !real_rev[n - 2 - i]) return;
-    const uint2 k = t.kids[i];
-    hrt_bvh_node nd;
-    memset(&nd, 0, sizeof(nd));
-    for (int c = 0; c < 2; ++c) {
-        const uint32_t kid = c == 0 ? k.x : k.y;
-        Box cb; int32_t ref;
-        if (kid & 0x80000000u) {
-            const uint32_t p = kid & 0x7fffffffu;
-            cb = tbox[vals[p]]; ref = (int32_t)~((leaf_pos[p] << 3) | 0u);
-        } else {
-            cb = t.nbox[kid];
-            if (real_rev[n - 2 - kid]) ref = (int32_t)dense_rev[n - 2 - kid];
-            else ref = (int32_t)~((start[kid] << 3) | (t.cnt[kid] - 1u));
-        }
-        cb = guarded(cb);
-        if (c == 0) { nd.c0_min_x = cb.mn[0]; nd.c0_max_x = cb.mx[0]; nd.c0_min_y = cb.mn[1]; nd.c0_max_y = cb.mx[1]; nd.c0_min_z = cb.mn[2]; nd.c0_max_z = cb.mx[2]; nd.child0 = ref; }
-        else { nd.c1_min_x = cb.mn[0]; nd.c1_max_x = cb.mx[0]; nd.c1_min_y = cb.mn[1]; nd.c1_max_y = cb.mx[1]; nd.c1_min_z = cb.mn[2]; nd.c1_max_z = cb.mx[2]; nd.child1 = ref; }
-    }
-    out[dense_rev[n - 2 - i]] = nd;
-}
-
 struct DevBufs {
     void* p[32]; int n = 0;
     ~DevBufs() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
@@ -382,8 +228,7 @@ struct DeviceGuard {      // the caller's current device is put back on every wa
 };
 #define LLAUNCH(name) do { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return lfail(HRT_ERR_HIP, std::string(name " launch: ") + hipGetErrorString(e_)); } while (0)
 
-enum { ALGO_LBVH = 0, ALGO_PLOC = 1 };
-hrt_status bvh_build_device_impl(int algo, int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
+hrt_status bvh_build_device_impl(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
                                  uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out) {
     if (!tri_pos || !nodes_out || !n_nodes_out || !order_out || !depth_out) return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: NULL argument");
     if (max_leaf < 1 || max_leaf > 8) return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: max_leaf must be 1..8");
@@ -425,69 +270,6 @@ hrt_status bvh_build_device_impl(int algo, int device, const float* tri_pos, uin
         char* tmp; LCHK(bufs.get(&tmp, tmp_bytes));
         LCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, d_keys_in, d_keys, d_vals_in, d_vals, (size_t)n, 0, 63, stream));
     }
-    if (algo == ALGO_PLOC) {
-        // ---- PLOC over the Morton order (see the head of this file)
-        uint32_t *d_cid[2], *d_nn, *d_cnt, *d_ctr, *d_leaf_pos, *d_order, *d_start;
-        Box* d_cbox[2];
-        unsigned long long *d_flags, *d_scan;
-        LCHK(bufs.get(&d_cid[0], (size_t)n)); LCHK(bufs.get(&d_cid[1], (size_t)n)); LCHK(bufs.get(&d_cbox[0], (size_t)n)); LCHK(bufs.get(&d_cbox[1], (size_t)n));
-        LCHK(bufs.get(&d_nn, (size_t)n)); LCHK(bufs.get(&d_flags, (size_t)n)); LCHK(bufs.get(&d_scan, (size_t)n)); LCHK(bufs.get(&d_cnt, (size_t)n_inner));
-        LCHK(bufs.get(&d_ctr, 4)); LCHK(bufs.get(&d_leaf_pos, (size_t)n)); LCHK(bufs.get(&d_order, (size_t)n)); LCHK(bufs.get(&d_start, (size_t)n_inner));
-        PlocTree t;
-        t.kids = d_kids; t.nbox = d_nbox; t.cnt = d_cnt; t.depth = d_depth; t.parent = d_pin; t.leaf_parent = d_pleaf;
-        size_t scan_bytes = 0;
-        LCHK(rocprim::exclusive_scan(nullptr, scan_bytes, d_flags, d_scan, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), stream));
-        char* scan_tmp; LCHK(bufs.get(&scan_tmp, scan_bytes));
-        // d_ctr: {m, created} of the pass being run, {m, created} the pass writes for the next one (ping-pong)
-        const uint32_t ctr0[4] = {(uint32_t)n, 0u, 0u, 0u};
-        LCHK(hipMemcpyAsync(d_ctr, ctr0, sizeof(ctr0), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_ploc_init, dim3(gb), dim3(256), 0, stream, d_tbox, d_vals, (uint32_t)n, d_cid[0], d_cbox[0]);
-        LLAUNCH("k_ploc_init");
-        uint32_t m = (uint32_t)n;
-        int cur = 0, passes = 0;
-        while (m > 1) {
-            if (++passes > 4 * 64) return lfail(HRT_ERR_HIP, "hrt_bvh_build_ploc: the clustering does not converge");   // (every pass merges at least one pair)
-            const unsigned g = (m + 255u) / 256u;
-            uint32_t* c_in = d_ctr + 2 * cur; uint32_t* c_out = d_ctr + 2 * (cur ^ 1);
-            hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, stream, d_cbox[cur], c_in, d_nn);
-            hipLaunchKernelGGL(k_ploc_flag, dim3(g), dim3(256), 0, stream, d_nn, c_in, d_flags);
-            LLAUNCH("k_ploc_nn / k_ploc_flag");
-            LCHK(rocprim::exclusive_scan(scan_tmp, scan_bytes, d_flags, d_scan, 0ull, (size_t)m, rocprim::plus<unsigned long long>(), stream));
-            hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(256), 0, stream, d_nn, d_flags, d_scan, d_cid[cur], d_cbox[cur], d_cid[cur ^ 1], d_cbox[cur ^ 1], t, max_leaf,
-                               c_in, c_in + 1, c_out, c_out + 1);
-            LLAUNCH("k_ploc_merge");
-            uint32_t next[2] = {0, 0};
-            LCHK(hipMemcpyAsync(next, c_out, sizeof(next), hipMemcpyDeviceToHost, stream));
-            LCHK(hipStreamSynchronize(stream));
-            if (next[0] == 0 || next[0] >= m) return lfail(HRT_ERR_HIP, "hrt_bvh_build_ploc: a pass made no progress");
-            m = next[0];
-            cur ^= 1;
-        }
-        // (n - 1 nodes were made; the root is the last one)
-        uint32_t* d_real_rev = d_real; uint32_t* d_dense_rev = d_dense;
-        hipLaunchKernelGGL(k_ploc_ranges, dim3(gb), dim3(256), 0, stream, t, d_vals, (uint32_t)n, max_leaf, d_leaf_pos, d_order, d_start, d_real_rev);
-        LLAUNCH("k_ploc_ranges");
-        {
-            size_t tmp_bytes = 0;
-            LCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, d_real_rev, d_dense_rev, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
-            char* tmp; LCHK(bufs.get(&tmp, tmp_bytes));
-            LCHK(rocprim::exclusive_scan(tmp, tmp_bytes, d_real_rev, d_dense_rev, 0u, (size_t)n_inner, rocprim::plus<uint32_t>(), stream));
-        }
-        LCHK(bufs.get(&d_out, (size_t)n_inner));
-        hipLaunchKernelGGL(k_ploc_emit, dim3(gi), dim3(256), 0, stream, t, d_tbox, d_vals, (uint32_t)n, max_leaf, d_leaf_pos, d_start, d_real_rev, d_dense_rev, d_out);
-        LLAUNCH("k_ploc_emit");
-        uint32_t last_real = 0, last_dense = 0, root_depth = 0;
-        LCHK(hipMemcpyAsync(&last_real, d_real_rev + (n_inner - 1), 4, hipMemcpyDeviceToHost, stream));
-        LCHK(hipMemcpyAsync(&last_dense, d_dense_rev + (n_inner - 1), 4, hipMemcpyDeviceToHost, stream));
-        LCHK(hipMemcpyAsync(&root_depth, d_depth + (n_inner - 1), 4, hipMemcpyDeviceToHost, stream));
-        LCHK(hipStreamSynchronize(stream));
-        const uint32_t n_nodes = last_dense + last_real;
-        LCHK(hipMemcpy(nodes_out, d_out, (size_t)n_nodes * sizeof(hrt_bvh_node), hipMemcpyDeviceToHost));
-        LCHK(hipMemcpy(order_out, d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        *n_nodes_out = n_nodes;
-        *depth_out = (int32_t)root_depth;
-        return HRT_OK;
-    }
     hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(256), 0, stream, d_keys, n, d_range, d_kids, d_pin, d_pleaf);
     LLAUNCH("k_hierarchy");
     hipLaunchKernelGGL(k_flag, dim3(gi), dim3(256), 0, stream, d_range, n_inner, max_leaf, d_real);
@@ -521,16 +303,8 @@ hrt_status bvh_build_device_impl(int algo, int device, const float* tri_pos, uin
 extern "C" hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
                                            uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out) {
     try {
-        return bvh_build_device_impl(ALGO_LBVH, device, tri_pos, n_tris, max_leaf, nodes_out, n_nodes_out, order_out, depth_out);
+        return bvh_build_device_impl(device, tri_pos, n_tris, max_leaf, nodes_out, n_nodes_out, order_out, depth_out);
     } catch (const std::bad_alloc&) { return lfail(HRT_ERR_OOM, "hrt_bvh_build_device: out of host memory"); }
     catch (const std::exception& e) { return lfail(HRT_ERR_INVALID, std::string("hrt_bvh_build_device: ") + e.what()); }
     catch (...) { return lfail(HRT_ERR_INVALID, "hrt_bvh_build_device: unknown C++ exception"); }
-}
-extern "C" hrt_status hrt_bvh_build_ploc(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
-                                         uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out) {
-    try {
-        return bvh_build_device_impl(ALGO_PLOC, device, tri_pos, n_tris, max_leaf, nodes_out, n_nodes_out, order_out, depth_out);
-    } catch (const std::bad_alloc&) { return lfail(HRT_ERR_OOM, "hrt_bvh_build_ploc: out of host memory"); }
-    catch (const std::exception& e) { return lfail(HRT_ERR_INVALID, std::string("hrt_bvh_build_ploc: ") + e.what()); }
-    catch (...) { return lfail(HRT_ERR_INVALID, "hrt_bvh_build_ploc: unknown C++ exception"); }
 }

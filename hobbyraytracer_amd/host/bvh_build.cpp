@@ -268,8 +268,10 @@ BVHNode::BVHNode(TriangleSoup& soup) {
         std::vector<uint32_t> order(n);
         uint32_t nNodes = 0; int32_t dDepth = 0;
         const hrt_status st = g_deviceBuild(g_deviceBuildDevice, soup.pos.data(), (uint32_t)n, (uint32_t)sb.maxLeaf, dn.data(), &nNodes, order.data(), &dDepth);
-        if (st != HRT_OK) throw FlattenError(st, "the device BVH builder failed (hrt_last_error() of libhrt_hip.so has the reason)");
-        if (dDepth <= 31 && nNodes != 0) {
+        if (st != HRT_OK && st != HRT_ERR_UNSUPPORTED) throw FlattenError(st, "the device BVH builder failed (hrt_last_error() of libhrt_hip.so has the reason)");
+        if (st == HRT_ERR_UNSUPPORTED)     // hrt_bvh_build_sah met a large node that needs the median split of the code below
+            std::cerr << "note: the GPU builder hands a mesh of " << n << " triangles back to the host SAH builder" << std::endl;
+        else if (dDepth <= 31 && nNodes != 0) {
         dn.resize(nNodes);
         TriangleSoup re;
         re.pos.resize(9 * n); re.nrm.resize(9 * n); re.uv.resize(6 * n);
@@ -288,7 +290,7 @@ BVHNode::BVHNode(TriangleSoup& soup) {
         }
         // a tree deeper than the traversal's stack (31 levels: clustered geometry inside a huge bound can do that to a Morton
         // tree) is not truncated and not a reason to fail the load: this mesh gets the host's SAH tree, whose depth is bounded
-        std::cerr << "note: the GPU-built BVH of a mesh of " << n << " triangles is " << dDepth << " levels deep (the traversal stack holds 31): "
+        else std::cerr << "note: the GPU-built BVH of a mesh of " << n << " triangles is " << dDepth << " levels deep (the traversal stack holds 31): "
                      "building this mesh's tree with the host SAH builder instead" << std::endl;
     }
     if (const char* e = std::getenv("HRT_BVH_TRI_COST")) sb.triCost = (float)std::atof(e);

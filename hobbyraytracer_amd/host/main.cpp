@@ -66,11 +66,11 @@ int main(int argc, char** argv) {
         else if (a == "--rccl") opt.force_rccl = true;
         else if (a == "--lens") opt.thin_lens = true;
         else if (a == "--obj-indices") { std::string v = next("--obj-indices"); setenv("HRT_OBJ_INDICES", v == "rebased" ? "rebased" : "reference", 1); }
-        else if (a == "--bvh") {     // who builds the meshes' culling trees: the host (binned SAH, default) or the GPU (ploc: SAH quality; lbvh: fastest)
+        else if (a == "--bvh") {     // who builds the meshes' culling trees: the host (binned SAH, default) or the GPU (gpu-sah: the same tree; lbvh: fastest to build, +16 % box tests)
             const std::string v = next("--bvh");
             if (v == "lbvh") hrt_host_set_bvh_builder(hrt_bvh_build_device, 0);
-            else if (v == "ploc") hrt_host_set_bvh_builder(hrt_bvh_build_ploc, 0);
-            else if (v != "sah") { std::cerr << "--bvh takes sah, ploc or lbvh" << std::endl; return -1; }
+            else if (v == "gpu-sah") hrt_host_set_bvh_builder(hrt_bvh_build_sah, 0);
+            else if (v != "sah") { std::cerr << "--bvh takes sah, gpu-sah or lbvh" << std::endl; return -1; }
         }
         else if (a == "--make-assets") makeAssets = next("--make-assets");
         else if (a == "--progressive") opt.pass_samples = std::atoi(next("--progressive"));

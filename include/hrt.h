@@ -277,10 +277,11 @@ typedef struct hrt_hit {          /* hitRecord (hittable.h:8-25) as seen by rayC
  * position of the leaf order the nodes' leaf codes refer to, *depth_out = inner-node levels (the traversal's stack need). */
 hrt_status hrt_bvh_build_device(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
                                 uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out);
-/* The same interface, a tree of the host SAH builder's quality: PLOC (parallel locally-ordered clustering: nearest neighbours by
- * union area inside a window of the Morton order, mutual pairs merged, repeated bottom-up; csrc/hrt_lbvh.hip). */
-hrt_status hrt_bvh_build_ploc(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
-                              uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out);
+/* The same interface, THE host builder's tree: host/bvh_build.cpp's binned-SAH algorithm run on the device with the same decisions
+ * and arithmetic (csrc/hrt_sahbvh.hip) -- the same topology, up to the order of the triangles inside a leaf.  HRT_ERR_UNSUPPORTED
+ * when a large node needs the host's median split (exhausted depth budget): the caller builds that mesh on the host. */
+hrt_status hrt_bvh_build_sah(int device, const float* tri_pos, uint32_t n_tris, uint32_t max_leaf, hrt_bvh_node* nodes_out,
+                             uint32_t* n_nodes_out, uint32_t* order_out, int32_t* depth_out);
 
 typedef struct hrt_scene hrt_scene;   /* device-resident flattened scene */
 

@@ -191,7 +191,7 @@ def test_cli_bvh_lbvh_gives_the_same_image_with_fixed_quirks(built, assets, scen
         outs.append(api.read_png(str(tmp_path / name)))
     assert np.array_equal(outs[0], outs[1])
     p = subprocess.run([api.CLI_PATH, "s.yaml", "--bvh", "octree"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 255 and "sah, ploc or lbvh" in p.stderr
+    assert p.returncode == 255 and "sah, gpu-sah or lbvh" in p.stderr
 
 
 def test_bench_under_torchrun_two_ranks_on_one_gpu(built, assets, scenes_dir, tmp_path):

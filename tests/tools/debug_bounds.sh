@@ -12,7 +12,8 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-
 if [ ! -f $out/libhrt_hip.so ] || [ hobbyraytracer_amd/csrc/hrt_hip.hip -nt $out/libhrt_hip.so ] || [ hobbyraytracer_amd/csrc/hrt_device.h -nt $out/libhrt_hip.so ]; then
     $HIPCC $FLAGS -c -o $out/hrt_hip.o hobbyraytracer_amd/csrc/hrt_hip.hip
     $HIPCC $FLAGS -c -o $out/hrt_lbvh.o hobbyraytracer_amd/csrc/hrt_lbvh.hip
-    $HIPCC $FLAGS -shared -o $out/libhrt_hip.so $out/hrt_hip.o $out/hrt_lbvh.o -ldl
+    $HIPCC $FLAGS -c -o $out/hrt_sahbvh.o hobbyraytracer_amd/csrc/hrt_sahbvh.hip
+    $HIPCC $FLAGS -shared -o $out/libhrt_hip.so $out/hrt_hip.o $out/hrt_lbvh.o $out/hrt_sahbvh.o -ldl
 fi
 export HRT_HIP_LIB=$PWD/$out/libhrt_hip.so
 export LD_LIBRARY_PATH=$PWD/$out:$LD_LIBRARY_PATH      # the CLI binary too (RUNPATH is searched after LD_LIBRARY_PATH)

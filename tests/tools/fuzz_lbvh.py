@@ -1,4 +1,4 @@
-"""usage (GPU box, repo root): python3 tests/tools/fuzz_lbvh.py N [seed] [lbvh|ploc] -- random triangle soups through hrt_bvh_build_device / hrt_bvh_build_ploc
+"""usage (GPU box, repo root): python3 tests/tools/fuzz_lbvh.py N [seed] [lbvh|sah] -- random triangle soups through hrt_bvh_build_device / hrt_bvh_build_sah
 (csrc/hrt_lbvh.hip): sizes 3..20000, coordinates from 1e-6 to 1e30 wide, clustered / coincident / degenerate triangles, signed zeros.
 Every tree is walked by tests/test_gpu_scenes.py _lbvh_check (permutation, leaf sizes, child boxes bit for bit, depth); trees deeper than
 the traversal stack are counted, not failed."""
@@ -31,8 +31,14 @@ for it in range(N):
         nodes, order, depth = api.bvh_build_device(tri, ml, algo=algo)
         _lbvh_check(tri, nodes, order, depth, ml)
         deep += depth > 31
+    except api.HrtError as e:
+        if e.status == api.HRT_ERR_UNSUPPORTED and algo == "sah":      # a large node needs the host's median split: handed back, by design
+            handed_back = globals().get("handed_back", 0) + 1
+            continue
+        bad += 1
+        print("BAD", it, n, kind, scale, ml, repr(e)[:200], flush=True)
     except Exception as e:
         bad += 1
         print("BAD", it, n, kind, scale, ml, repr(e)[:200], flush=True)
     if (it + 1) % 200 == 0: print("progress", it + 1, "bad", bad, "deeper than 31:", deep, flush=True)
-print("done", N, "bad", bad, "deeper than 31:", deep)
+print("done", N, "bad", bad, "deeper than 31:", deep, "handed back to the host:", globals().get("handed_back", 0))
