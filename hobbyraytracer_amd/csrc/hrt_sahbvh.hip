@@ -14,14 +14,16 @@
 //     k_sah_bins     block per chunk: 3 x 16 bins (box + count) in LDS, folded into the node's with ordered-integer atomics
 //     k_sah_eval     thread per node: the sweep over the bins, leaf / split decision, node allocation, the two children
 //     k_sah_count / k_sah_scatter   block per chunk: partition of the node's index range by "bin <= best bin"
-//   small nodes: k_sah_small, one THREAD per subtree, the host's recursion with an explicit stack (a subtree of 128 triangles
-//     is ~90 nodes and ~30 k operations; a 100 k-triangle mesh has ~1500 of them side by side)
+//   small nodes: k_sah_small, one WAVE per subtree, the host's recursion with an explicit stack; the subtree's triangles sit in
+//     LDS and the 64 lanes share every pass over them (one thread per subtree took 8 ms for the 100 k-triangle bust: a chain
+//     of ~4000 dependent loads per thread)
 //
 // A node whose SAH is not allowed by the depth budget or has no valid split while its centroids differ needs the host's
-// nth_element median split: inside k_sah_small it is an insertion sort of the (small) range; in the large phase the build
+// nth_element median split: inside k_sah_small it is an insertion sort of the (small) range by one lane; in the large phase the build
 // is given back to the caller (HRT_ERR_UNSUPPORTED: host/bvh_build.cpp then builds that mesh itself).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -125,25 +127,26 @@ __global__ void k_sah_plan(const Work* __restrict__ work, uint32_t n_work, WorkS
     }
 }
 
+__device__ inline float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64)); return v; }
+__device__ inline float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
 __global__ __launch_bounds__(256) void k_sah_bounds(const Work* __restrict__ work, const uint32_t* __restrict__ chunk_work, const uint32_t* __restrict__ chunk_start,
-                                                    const Ref* __restrict__ refs, const uint32_t* __restrict__ idx, WorkStats* __restrict__ stats) {
-    __shared__ uint32_t s[12];
-    if (threadIdx.x < 12) s[threadIdx.x] = (threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9)) ? 0xffffffffu : 0u;
-    __syncthreads();
+                                                    const Ref* __restrict__ refs, const uint32_t* __restrict__ idx, WorkStats* __restrict__ stats, const Counters* __restrict__ ctr) {
+    if (blockIdx.x >= ctr->n_chunks) return;
     const uint32_t w = chunk_work[blockIdx.x], start = chunk_start[blockIdx.x];
     const uint32_t end = min(start + HRT_SAH_CHUNK, work[w].hi);
+    Box3 b, c;
+    box_reset(b); box_reset(c);
     for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) {
         const Ref r = refs[idx[i]];
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&s[a], f2o(r.mn[a])); atomicMax(&s[3 + a], f2o(r.mx[a]));
-            atomicMin(&s[6 + a], f2o(r.c[a])); atomicMax(&s[9 + a], f2o(r.c[a]));
-        }
+        box_grow(b, r.mn, r.mx); box_grow(c, r.c, r.c);
     }
-    __syncthreads();
-    if (threadIdx.x < 12) {
-        uint32_t* g = (uint32_t*)&stats[w];
-        const bool is_min = threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9);
-        if (is_min) atomicMin(&g[threadIdx.x], s[threadIdx.x]); else atomicMax(&g[threadIdx.x], s[threadIdx.x]);
+    // registers -> wave (shuffles) -> the node's words (one atomic per wave and word; an empty wave's +-inf changes nothing)
+    uint32_t* g = (uint32_t*)&stats[w];
+    for (int a = 0; a < 3; ++a) {
+        const float v0 = wave_min(b.mn[a]), v1 = wave_max(b.mx[a]), v2 = wave_min(c.mn[a]), v3 = wave_max(c.mx[a]);
+        if ((threadIdx.x & 63u) == 0 && v0 <= v1) {
+            atomicMin(&g[a], f2o(v0)); atomicMax(&g[3 + a], f2o(v1)); atomicMin(&g[6 + a], f2o(v2)); atomicMax(&g[9 + a], f2o(v3));
+        }
     }
 }
 
@@ -153,8 +156,9 @@ __device__ inline int bin_of(float c, float cmin, float scale) {       // SahBui
 }
 
 __global__ __launch_bounds__(256) void k_sah_bins(const Work* __restrict__ work, const uint32_t* __restrict__ chunk_work, const uint32_t* __restrict__ chunk_start,
-                                                  const Ref* __restrict__ refs, const uint32_t* __restrict__ idx, WorkStats* __restrict__ stats) {
+                                                  const Ref* __restrict__ refs, const uint32_t* __restrict__ idx, WorkStats* __restrict__ stats, const Counters* __restrict__ ctr) {
     __shared__ uint32_t s_mn[3][HRT_SAH_BINS][3], s_mx[3][HRT_SAH_BINS][3], s_cnt[3][HRT_SAH_BINS];
+    if (blockIdx.x >= ctr->n_chunks) return;
     for (uint32_t i = threadIdx.x; i < 3 * HRT_SAH_BINS * 3; i += blockDim.x) { ((uint32_t*)s_mn)[i] = 0xffffffffu; ((uint32_t*)s_mx)[i] = 0u; }
     for (uint32_t i = threadIdx.x; i < 3 * HRT_SAH_BINS; i += blockDim.x) ((uint32_t*)s_cnt)[i] = 0u;
     __syncthreads();
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(64) void k_sah_eval(const Work* __restrict__ work, 
 // partition of a large node's range: count the "left" refs of every chunk, then scatter
 __global__ __launch_bounds__(256) void k_sah_count(const Work* __restrict__ work, const uint32_t* __restrict__ chunk_work, const uint32_t* __restrict__ chunk_start,
                                                    const Ref* __restrict__ refs, const uint32_t* __restrict__ idx, const WorkStats* __restrict__ stats,
-                                                   uint32_t* __restrict__ chunk_left) {
+                                                   uint32_t* __restrict__ chunk_left, const Counters* __restrict__ ctr) {
     __shared__ uint32_t s;
+    if (blockIdx.x >= ctr->n_chunks) return;
     if (threadIdx.x == 0) s = 0;
     __syncthreads();
     const uint32_t w = chunk_work[blockIdx.x], start = chunk_start[blockIdx.x];
@@ -275,8 +280,10 @@ __global__ __launch_bounds__(256) void k_sah_count(const Work* __restrict__ work
 }
 __global__ __launch_bounds__(256) void k_sah_scatter(const Work* __restrict__ work, const uint32_t* __restrict__ chunk_work, const uint32_t* __restrict__ chunk_start,
                                                      const uint32_t* __restrict__ work_first_chunk, const Ref* __restrict__ refs, const uint32_t* __restrict__ idx_in,
-                                                     uint32_t* __restrict__ idx_out, const WorkStats* __restrict__ stats, const uint32_t* __restrict__ chunk_left) {
+                                                     uint32_t* __restrict__ idx_out, const WorkStats* __restrict__ stats, const uint32_t* __restrict__ chunk_left,
+                                                     const Counters* __restrict__ ctr) {
     __shared__ uint32_t s_left, s_right;
+    if (blockIdx.x >= ctr->n_chunks) return;
     const uint32_t w = chunk_work[blockIdx.x], start = chunk_start[blockIdx.x];
     const uint32_t end = min(start + HRT_SAH_CHUNK, work[w].hi);
     const int axis = stats[w].axis;
@@ -314,57 +321,118 @@ __global__ __launch_bounds__(256) void k_sah_scatter(const Work* __restrict__ wo
     }
 }
 
-// One thread per small subtree: SahBuilder::build with an explicit stack.  idx[lo, hi) is this thread's alone.
-__global__ __launch_bounds__(64) void k_sah_small(const Work* __restrict__ small, uint32_t n_small, const Ref* __restrict__ refs, uint32_t* __restrict__ idx,
-                                                  uint32_t max_leaf, hrt_bvh_node* __restrict__ nodes, Counters* __restrict__ ctr) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_small) return;
-    const float triCost = 1.3f, boxCost = 1.0f;
+// One WAVE per small subtree: SahBuilder::build with an explicit stack, the 64 lanes sharing each node's passes over its
+// triangles (at most two per lane).  The subtree's refs are copied into LDS once; `lidx` is the wave's private index array
+// (positions into that copy), permuted in place and written back to idx[lo, hi) at the end.
+#define HRT_SAH_WAVES 4
+struct SmallLds {
+    float ref[9][HRT_SAH_SMALL];                       // mn.xyz, mx.xyz, c.xyz of the subtree's triangles (SoA)
+    uint32_t gidx[HRT_SAH_SMALL];                      // their indices in the mesh
+    uint32_t lidx[HRT_SAH_SMALL];
+    uint32_t bin_mn[3][HRT_SAH_BINS][3], bin_mx[3][HRT_SAH_BINS][3], bin_cnt[3][HRT_SAH_BINS];
     Work stack[40];
+};
+__device__ inline unsigned lanes_below_mask(unsigned long long m, unsigned lane) { return (unsigned)__popcll(m & ((1ull << lane) - 1ull)); }
+__global__ __launch_bounds__(64 * HRT_SAH_WAVES) void k_sah_small(const Work* __restrict__ small, uint32_t n_small, const Ref* __restrict__ refs, uint32_t* __restrict__ idx,
+                                                                 uint32_t max_leaf, hrt_bvh_node* __restrict__ nodes, Counters* __restrict__ ctr) {
+    __shared__ SmallLds lds_all[HRT_SAH_WAVES];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * HRT_SAH_WAVES + wv;
+    if (s >= n_small) return;                           // (whole waves leave: no block-wide barrier below)
+    SmallLds& L = lds_all[wv];
+    const float triCost = 1.3f, boxCost = 1.0f;
+    const Work root = small[s];
+    const uint32_t base = root.lo, total = root.hi - root.lo;       // <= HRT_SAH_SMALL
+    for (uint32_t i = lane; i < total; i += 64) {
+        const uint32_t t = idx[base + i];
+        const Ref r = refs[t];
+        L.gidx[i] = t; L.lidx[i] = i;
+        for (int a = 0; a < 3; ++a) { L.ref[a][i] = r.mn[a]; L.ref[3 + a][i] = r.mx[a]; L.ref[6 + a][i] = r.c[a]; }
+    }
     int sp = 0;
-    stack[sp++] = small[s];
+    if (lane == 0) { Work r0 = root; r0.lo = 0; r0.hi = total; L.stack[0] = r0; }
+    sp = 1;
     uint32_t my_max_depth = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     while (sp > 0) {
-        const Work wk = stack[--sp];
+        --sp;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const Work wk = L.stack[sp];                    // (the same word in every lane)
         const uint32_t lo = wk.lo, hi = wk.hi, n = hi - lo;
+        // ---- bounds (each lane: positions lo + lane and lo + lane + 64)
         Box3 outBox, cb;
         box_reset(outBox); box_reset(cb);
-        for (uint32_t i = lo; i < hi; ++i) { const Ref& r = refs[idx[i]]; box_grow(outBox, r.mn, r.mx); box_grow(cb, r.c, r.c); }
-        if (n == 1) { set_child(nodes, wk.parent, wk.side, outBox, leaf_ref(lo, 1)); continue; }
+        for (uint32_t p = lo + lane; p < hi; p += 64) {
+            const uint32_t k = L.lidx[p];
+            float mn[3] = {L.ref[0][k], L.ref[1][k], L.ref[2][k]}, mx[3] = {L.ref[3][k], L.ref[4][k], L.ref[5][k]}, c[3] = {L.ref[6][k], L.ref[7][k], L.ref[8][k]};
+            box_grow(outBox, mn, mx); box_grow(cb, c, c);
+        }
+        for (int a = 0; a < 3; ++a) { outBox.mn[a] = wave_min(outBox.mn[a]); outBox.mx[a] = wave_max(outBox.mx[a]); cb.mn[a] = wave_min(cb.mn[a]); cb.mx[a] = wave_max(cb.mx[a]); }
+        if (n == 1) { if (lane == 0) set_child(nodes, wk.parent, wk.side, outBox, leaf_ref(base + lo, 1)); continue; }
         uint32_t mid = lo;
-        bool haveSplit = false;
+        bool haveSplit = false, leaf = false;
         int axis = 0;
         { float ext = -1; for (int a = 0; a < 3; ++a) { const float e = cb.mx[a] - cb.mn[a]; if (e > ext) { ext = e; axis = a; } } }
         const float leafCost = triCost * n;
         const bool sahAllowed = wk.depth + ceil_log2(n) + 1 < HRT_SAH_LEVELS;
-        bool leaf = false;
         if (sahAllowed && n > 2) {
+            // ---- bins of the three axes in one pass (LDS atomics on ordered integers)
+            for (uint32_t i = lane; i < 3 * HRT_SAH_BINS * 3; i += 64) { ((uint32_t*)L.bin_mn)[i] = 0xffffffffu; ((uint32_t*)L.bin_mx)[i] = 0u; }
+            if (lane < 3 * HRT_SAH_BINS) ((uint32_t*)L.bin_cnt)[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float scale[3]; bool use[3];
+            for (int a = 0; a < 3; ++a) { const float e = cb.mx[a] - cb.mn[a]; use[a] = e > 0; scale[a] = HRT_SAH_BINS / e; }
+            for (uint32_t p = lo + lane; p < hi; p += 64) {
+                const uint32_t k = L.lidx[p];
+                for (int a = 0; a < 3; ++a) {
+                    if (!use[a]) continue;
+                    const int bk = bin_of(L.ref[6 + a][k], cb.mn[a], scale[a]);
+                    for (int d = 0; d < 3; ++d) { atomicMin(&L.bin_mn[a][bk][d], f2o(L.ref[d][k])); atomicMax(&L.bin_mx[a][bk][d], f2o(L.ref[3 + d][k])); }
+                    atomicAdd(&L.bin_cnt[a][bk], 1u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // ---- the sweep: lane a prices axis a; combined in axis order with "first strictly better wins"
+            float myCost = __builtin_huge_valf(); int myAxis = -1, myBin = -1;
+            if (lane < 3 && use[lane]) {
+                Box3 bb[HRT_SAH_BINS]; uint32_t bc[HRT_SAH_BINS];
+                for (int k = 0; k < HRT_SAH_BINS; ++k) {
+                    bc[k] = L.bin_cnt[lane][k];
+                    if (bc[k]) for (int d = 0; d < 3; ++d) { bb[k].mn[d] = o2f(L.bin_mn[lane][k][d]); bb[k].mx[d] = o2f(L.bin_mx[lane][k][d]); }
+                    else box_reset(bb[k]);
+                }
+                sweep_axis((int)lane, bb, bc, myCost, myAxis, myBin);
+            }
             float bestCost = __builtin_huge_valf(); int bestAxis = -1, bestBin = -1;
             for (int a = 0; a < 3; ++a) {
-                const float e = cb.mx[a] - cb.mn[a];
-                if (!(e > 0)) continue;
-                Box3 bb[HRT_SAH_BINS]; uint32_t bc[HRT_SAH_BINS];
-                for (int k = 0; k < HRT_SAH_BINS; ++k) { box_reset(bb[k]); bc[k] = 0; }
-                const float scale = HRT_SAH_BINS / e;
-                for (uint32_t i = lo; i < hi; ++i) {
-                    const Ref& r = refs[idx[i]];
-                    const int k = bin_of(r.c[a], cb.mn[a], scale);
-                    box_grow(bb[k], r.mn, r.mx); bc[k]++;
-                }
-                sweep_axis(a, bb, bc, bestCost, bestAxis, bestBin);
+                const float c = __shfl(myCost, a, 64); const int ax = __shfl(myAxis, a, 64), bn = __shfl(myBin, a, 64);
+                if (ax >= 0 && c < bestCost) { bestCost = c; bestAxis = ax; bestBin = bn; }
             }
             if (bestAxis >= 0) {
                 const float parentArea = half_area(outBox);
                 const float splitCost = 2 * boxCost + triCost * bestCost / (parentArea > 0 ? parentArea : 1.0f);
                 if (n <= max_leaf && leafCost <= splitCost) leaf = true;
                 else {
-                    const float scale = HRT_SAH_BINS / (cb.mx[bestAxis] - cb.mn[bestAxis]);
-                    uint32_t i = lo, j = hi;               // std::partition by "bin <= bestBin"
-                    while (i < j) {
-                        if (bin_of(refs[idx[i]].c[bestAxis], cb.mn[bestAxis], scale) <= bestBin) ++i;
-                        else { --j; const uint32_t t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+                    // ---- stable partition by "bin <= bestBin": ranks from ballots, two positions per lane, values held in registers
+                    const float sc = HRT_SAH_BINS / (cb.mx[bestAxis] - cb.mn[bestAxis]);
+                    uint32_t v[2] = {0, 0}; bool live[2], left[2];
+                    unsigned long long ml[2], mr[2];
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t p = lo + (uint32_t)r * 64u + lane;
+                        live[r] = p < hi; left[r] = false;
+                        if (live[r]) { v[r] = L.lidx[p]; left[r] = bin_of(L.ref[6 + bestAxis][v[r]], cb.mn[bestAxis], sc) <= bestBin; }
+                        ml[r] = __ballot(live[r] && left[r]); mr[r] = __ballot(live[r] && !left[r]);
                     }
-                    mid = i;
+                    const uint32_t nl = (uint32_t)(__popcll(ml[0]) + __popcll(ml[1]));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (int r = 0; r < 2; ++r) {
+                        if (!live[r]) continue;
+                        const uint32_t before_l = (r ? (uint32_t)__popcll(ml[0]) : 0u) + lanes_below_mask(ml[r], lane);
+                        const uint32_t before_r = (r ? (uint32_t)__popcll(mr[0]) : 0u) + lanes_below_mask(mr[r], lane);
+                        L.lidx[left[r] ? lo + before_l : lo + nl + before_r] = v[r];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    mid = lo + nl;
                     haveSplit = mid > lo && mid < hi;
                 }
             }
@@ -372,26 +440,36 @@ __global__ __launch_bounds__(64) void k_sah_small(const Work* __restrict__ small
         if (!leaf && !haveSplit) {
             if (n <= max_leaf) leaf = true;
             else {
-                // balanced median split on the widest centroid axis (std::nth_element on the host): the range is small, sort it
+                // balanced median split on the widest centroid axis (std::nth_element on the host): a small range, sorted by lane 0
                 mid = lo + n / 2;
-                for (uint32_t i = lo + 1; i < hi; ++i) {
-                    const uint32_t t = idx[i]; const float key = refs[t].c[axis];
-                    uint32_t j = i;
-                    while (j > lo && refs[idx[j - 1]].c[axis] > key) { idx[j] = idx[j - 1]; --j; }
-                    idx[j] = t;
+                if (lane == 0) {
+                    for (uint32_t i = lo + 1; i < hi; ++i) {
+                        const uint32_t t = L.lidx[i]; const float key = L.ref[6 + axis][t];
+                        uint32_t j = i;
+                        while (j > lo && L.ref[6 + axis][L.lidx[j - 1]] > key) { L.lidx[j] = L.lidx[j - 1]; --j; }
+                        L.lidx[j] = t;
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
-        if (leaf) { set_child(nodes, wk.parent, wk.side, outBox, leaf_ref(lo, n)); continue; }
-        const uint32_t me = atomicAdd(&ctr->n_nodes, 1u);
+        if (leaf) { if (lane == 0) set_child(nodes, wk.parent, wk.side, outBox, leaf_ref(base + lo, n)); continue; }
+        uint32_t me = 0;
+        if (lane == 0) me = atomicAdd(&ctr->n_nodes, 1u);
+        me = (uint32_t)__shfl((int)me, 0, 64);
         if ((uint32_t)wk.depth > my_max_depth) my_max_depth = (uint32_t)wk.depth;
-        set_child(nodes, wk.parent, wk.side, outBox, (int32_t)me);
-        if (sp + 2 > 40) { atomicExch(&ctr->give_up, 2u); return; }      // (cannot happen: the depth budget bounds the stack at 32)
-        Work c; c.parent = me; c.depth = wk.depth + 1;
-        c.lo = mid; c.hi = hi; c.side = 1; stack[sp++] = c;
-        c.lo = lo; c.hi = mid; c.side = 0; stack[sp++] = c;
+        if (sp + 2 > 40) { if (lane == 0) atomicExch(&ctr->give_up, 2u); return; }      // (cannot happen: the depth budget bounds the stack at 32)
+        if (lane == 0) {
+            set_child(nodes, wk.parent, wk.side, outBox, (int32_t)me);
+            Work c; c.parent = me; c.depth = wk.depth + 1;
+            c.lo = mid; c.hi = hi; c.side = 1; L.stack[sp] = c;
+            c.lo = lo; c.hi = mid; c.side = 0; L.stack[sp + 1] = c;
+        }
+        sp += 2;
     }
-    if (my_max_depth) atomicMax(&ctr->max_depth, my_max_depth);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t i = lane; i < total; i += 64) idx[base + i] = L.gidx[L.lidx[i]];
+    if (lane == 0 && my_max_depth) atomicMax(&ctr->max_depth, my_max_depth);
 }
 
 struct DevBufs {
@@ -436,13 +514,24 @@ hrt_status build_sah_impl(int device, const float* tri_pos, uint32_t n, uint32_t
     const size_t max_large = (size_t)n / HRT_SAH_SMALL + 2;              // large nodes of one level (disjoint ranges of more than SMALL triangles)
     const size_t max_chunks = (size_t)n / HRT_SAH_CHUNK + max_large + 2;
     const size_t max_small = (size_t)n + 2;                               // (every small range holds at least one triangle)
+    // one allocation, carved up (fifteen hipMalloc / hipFree pairs were 2 ms of a 100 k-triangle build)
     DevBufs bufs;
     float* d_pos; Ref* d_refs; uint32_t *d_idx[2], *d_chunk_work, *d_chunk_start, *d_first_chunk, *d_chunk_left;
     Work *d_work[2], *d_small; WorkStats* d_stats; Counters* d_ctr; hrt_bvh_node* d_nodes;
-    SCHK(bufs.get(&d_pos, 9ull * n)); SCHK(bufs.get(&d_refs, (size_t)n)); SCHK(bufs.get(&d_idx[0], (size_t)n)); SCHK(bufs.get(&d_idx[1], (size_t)n));
-    SCHK(bufs.get(&d_chunk_work, max_chunks)); SCHK(bufs.get(&d_chunk_start, max_chunks)); SCHK(bufs.get(&d_chunk_left, max_chunks)); SCHK(bufs.get(&d_first_chunk, max_large + 1));
-    SCHK(bufs.get(&d_work[0], max_large)); SCHK(bufs.get(&d_work[1], max_large)); SCHK(bufs.get(&d_small, max_small)); SCHK(bufs.get(&d_stats, max_large));
-    SCHK(bufs.get(&d_ctr, 1)); SCHK(bufs.get(&d_nodes, (size_t)n));
+    {
+        size_t off = 0;
+        auto place = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_pos = place(9ull * n * sizeof(float)), o_refs = place((size_t)n * sizeof(Ref)), o_i0 = place((size_t)n * 4), o_i1 = place((size_t)n * 4),
+                     o_cw = place(max_chunks * 4), o_cs = place(max_chunks * 4), o_cl = place(max_chunks * 4), o_fc = place((max_large + 1) * 4),
+                     o_w0 = place(max_large * sizeof(Work)), o_w1 = place(max_large * sizeof(Work)), o_sm = place(max_small * sizeof(Work)),
+                     o_st = place(max_large * sizeof(WorkStats)), o_ct = place(sizeof(Counters)), o_nd = place((size_t)n * sizeof(hrt_bvh_node));
+        char* base = nullptr;
+        SCHK(bufs.get(&base, off));
+        d_pos = (float*)(base + o_pos); d_refs = (Ref*)(base + o_refs); d_idx[0] = (uint32_t*)(base + o_i0); d_idx[1] = (uint32_t*)(base + o_i1);
+        d_chunk_work = (uint32_t*)(base + o_cw); d_chunk_start = (uint32_t*)(base + o_cs); d_chunk_left = (uint32_t*)(base + o_cl); d_first_chunk = (uint32_t*)(base + o_fc);
+        d_work[0] = (Work*)(base + o_w0); d_work[1] = (Work*)(base + o_w1); d_small = (Work*)(base + o_sm); d_stats = (WorkStats*)(base + o_st);
+        d_ctr = (Counters*)(base + o_ct); d_nodes = (hrt_bvh_node*)(base + o_nd);
+    }
     SCHK(hipMemcpyAsync(d_pos, tri_pos, 9ull * n * sizeof(float), hipMemcpyHostToDevice, stream));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), stream));
     SCHK(hipMemsetAsync(d_nodes, 0, (size_t)n * sizeof(hrt_bvh_node), stream));
@@ -464,21 +553,19 @@ hrt_status build_sah_impl(int device, const float* tri_pos, uint32_t n, uint32_t
         if (level > 64) return sfail(HRT_ERR_HIP, "hrt_bvh_build_sah: the large-node phase does not end");
         hipLaunchKernelGGL(k_sah_plan, dim3(1), dim3(256), 0, stream, d_work[wcur], n_work, d_stats, d_chunk_work, d_chunk_start, d_first_chunk, d_ctr);
         SLAUNCH("k_sah_plan");
-        // (the chunk count is bounded by the host: ranges are disjoint)
-        uint32_t n_chunks = 0;
-        SCHK(hipMemcpyAsync(&n_chunks, &d_ctr->n_chunks, 4, hipMemcpyDeviceToHost, stream));
-        SCHK(hipStreamSynchronize(stream));
-        if (n_chunks == 0 || n_chunks > max_chunks) return sfail(HRT_ERR_HIP, "hrt_bvh_build_sah: bad chunk count");
-        hipLaunchKernelGGL(k_sah_bounds, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_refs, d_idx[cur], d_stats);
-        hipLaunchKernelGGL(k_sah_bins, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_refs, d_idx[cur], d_stats);
+        // the chunk count stays on the device: the ranges are disjoint, so n / CHUNK + n_work bounds it, and the blocks beyond
+        // ctr->n_chunks leave at once (one host synchronisation per level instead of two)
+        const uint32_t n_chunks = (uint32_t)std::min<size_t>(max_chunks, (size_t)n / HRT_SAH_CHUNK + n_work);
+        hipLaunchKernelGGL(k_sah_bounds, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_refs, d_idx[cur], d_stats, d_ctr);
+        hipLaunchKernelGGL(k_sah_bins, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_refs, d_idx[cur], d_stats, d_ctr);
         SLAUNCH("k_sah_bounds / k_sah_bins");
         hipLaunchKernelGGL(k_sah_eval, dim3((n_work + 63) / 64), dim3(64), 0, stream, d_work[wcur], n_work, d_stats, max_leaf, d_nodes, d_work[wcur ^ 1], d_small, d_ctr);
-        hipLaunchKernelGGL(k_sah_count, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_refs, d_idx[cur], d_stats, d_chunk_left);
+        hipLaunchKernelGGL(k_sah_count, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_refs, d_idx[cur], d_stats, d_chunk_left, d_ctr);
         SLAUNCH("k_sah_eval / k_sah_count");
         // ranges of this level's large nodes are rewritten into the other index array; everything else is copied first
         SCHK(hipMemcpyAsync(d_idx[cur ^ 1], d_idx[cur], (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(k_sah_scatter, dim3(n_chunks), dim3(256), 0, stream, d_work[wcur], d_chunk_work, d_chunk_start, d_first_chunk, d_refs, d_idx[cur], d_idx[cur ^ 1],
-                           d_stats, d_chunk_left);
+                           d_stats, d_chunk_left, d_ctr);
         SLAUNCH("k_sah_scatter");
         cur ^= 1;
         SCHK(hipMemcpyAsync(&h, d_ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -493,7 +580,8 @@ hrt_status build_sah_impl(int device, const float* tri_pos, uint32_t n, uint32_t
     SCHK(hipMemcpyAsync(&h, d_ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
     SCHK(hipStreamSynchronize(stream));
     if (h.n_small) {
-        hipLaunchKernelGGL(k_sah_small, dim3((h.n_small + 63) / 64), dim3(64), 0, stream, d_small, h.n_small, d_refs, d_idx[cur], max_leaf, d_nodes, d_ctr);
+        hipLaunchKernelGGL(k_sah_small, dim3((h.n_small + HRT_SAH_WAVES - 1) / HRT_SAH_WAVES), dim3(64 * HRT_SAH_WAVES), 0, stream, d_small, h.n_small, d_refs, d_idx[cur],
+                           max_leaf, d_nodes, d_ctr);
         SLAUNCH("k_sah_small");
     }
     SCHK(hipMemcpyAsync(&h, d_ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
