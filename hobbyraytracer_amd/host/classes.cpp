@@ -243,7 +243,9 @@ bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& e
     std::string line;
     struct Idx { int v, t, n; };
     std::vector<Idx> face;
-    std::vector<size_t> subMeshStart;   // first triangle of every aiMesh Assimp would make (object / group / material runs with faces)
+    std::vector<size_t> subMeshCorner;  // first corner of every aiMesh Assimp would make (object / group / material runs with faces)
+    std::vector<float> cPos, cNrm, cUv; // one vertex per face corner, in file order (= the aiMeshes' vertex arrays, concatenated: mesh.cpp:108-110)
+    std::vector<uint32_t> triIdx, triSub;   // the triangulated faces: three corner indices each, and the sub-mesh they belong to
     bool newRun = true;
     int lineNo = 0;
     while (std::getline(f, line)) {
@@ -299,35 +301,42 @@ bool Mesh::importFile(const std::string& path, TriangleSoup& out, std::string& e
                 face.push_back(ix);
             }
             if (face.size() < 3) continue;  // points / lines are dropped by Triangulate
-            if (newRun) { subMeshStart.push_back(out.pos.size() / 9); newRun = false; }
+            if (newRun) { subMeshCorner.push_back(cPos.size() / 3); newRun = false; }
+            // Assimp's OBJ importer makes one vertex per face CORNER (no aiProcess_JoinIdenticalVertices, mesh.cpp:56) and
+            // aiProcess_Triangulate then indexes those: a polygon's corners c0..ck-1 become the fan (c0, ci, ci+1) -- its choice for a
+            // convex polygon of up to four corners; larger or concave ones are ear-clipped there, which covers the same area
+            const uint32_t c0 = (uint32_t)(cPos.size() / 3);
+            for (const Idx& ix : face) {
+                cPos.push_back(v[3 * ix.v]); cPos.push_back(v[3 * ix.v + 1]); cPos.push_back(v[3 * ix.v + 2]);
+                if (ix.n >= 0) { cNrm.push_back(vn[3 * ix.n]); cNrm.push_back(vn[3 * ix.n + 1]); cNrm.push_back(vn[3 * ix.n + 2]); }
+                else { cNrm.push_back(0); cNrm.push_back(0); cNrm.push_back(0); }
+                if (ix.t >= 0) { cUv.push_back(vt[2 * ix.t]); cUv.push_back(1.0f - vt[2 * ix.t + 1]); }      // aiProcess_FlipUVs
+                else { cUv.push_back(0); cUv.push_back(0); }
+            }
             for (size_t k = 1; k + 1 < face.size(); ++k) {
-                const Idx tri[3] = {face[0], face[k], face[k + 1]};
-                for (const Idx& ix : tri) {
-                    out.pos.push_back(v[3 * ix.v]); out.pos.push_back(v[3 * ix.v + 1]); out.pos.push_back(v[3 * ix.v + 2]);
-                    if (ix.n >= 0) { out.nrm.push_back(vn[3 * ix.n]); out.nrm.push_back(vn[3 * ix.n + 1]); out.nrm.push_back(vn[3 * ix.n + 2]); }
-                    else { out.nrm.push_back(0); out.nrm.push_back(0); out.nrm.push_back(0); }
-                    if (ix.t >= 0) { out.uv.push_back(vt[2 * ix.t]); out.uv.push_back(1.0f - vt[2 * ix.t + 1]); }
-                    else { out.uv.push_back(0); out.uv.push_back(0); }
-                }
+                triIdx.push_back(c0); triIdx.push_back(c0 + (uint32_t)k); triIdx.push_back(c0 + (uint32_t)k + 1);
+                triSub.push_back((uint32_t)subMeshCorner.size() - 1);
             }
         }
         else if ((s[0] == 'o' || s[0] == 'g') && (s[1] == ' ' || s[1] == '\t' || s[1] == 0)) newRun = true;
         else if (std::strncmp(s, "usemtl", 6) == 0 && (s[6] == ' ' || s[6] == '\t')) newRun = true;
     }
-    if (out.pos.empty()) { err = "OBJ: file contains no faces: " + path; return false; }
-    if (objIndexQuirk() && subMeshStart.size() > 1) {   // Q-8, see above
-        const TriangleSoup all = out;
-        const size_t total = all.pos.size() / 9;
-        for (size_t m = 1; m < subMeshStart.size(); ++m) {
-            const size_t first = subMeshStart[m], end = m + 1 < subMeshStart.size() ? subMeshStart[m + 1] : total;
-            for (size_t j = first; j < end; ++j) {       // triangle j - first of this sub-mesh <- triangle j - first of the file
-                const size_t src = j - first;
-                std::copy(all.pos.begin() + 9 * src, all.pos.begin() + 9 * src + 9, out.pos.begin() + 9 * j);
-                std::copy(all.nrm.begin() + 9 * src, all.nrm.begin() + 9 * src + 9, out.nrm.begin() + 9 * j);
-                std::copy(all.uv.begin() + 6 * src, all.uv.begin() + 6 * src + 6, out.uv.begin() + 6 * j);
-            }
+    if (triIdx.empty()) { err = "OBJ: file contains no faces: " + path; return false; }
+    // Q-8 (mesh.cpp:111-114): every aiMesh's indices are local to ITS vertex array, and the reference appends them to one list
+    // without adding the vertices already there -- so the corners of sub-mesh m > 0 are looked up at the START of the concatenated
+    // vertex array (the corners of the first sub-meshes), vertex by vertex: a file of triangles only shows whole triangles of the
+    // first sub-mesh again, one with quads mixes corners of different faces.  Reproduced at that level: local index = corner index
+    // minus the sub-mesh's first corner.
+    const bool quirk = objIndexQuirk() && subMeshCorner.size() > 1;
+    const size_t nTri = triSub.size();
+    out.pos.resize(9 * nTri); out.nrm.resize(9 * nTri); out.uv.resize(6 * nTri);
+    for (size_t t = 0; t < nTri; ++t)
+        for (int k = 0; k < 3; ++k) {
+            size_t c = triIdx[3 * t + k];
+            if (quirk) c -= subMeshCorner[triSub[t]];      // < the sub-mesh's own corner count <= all corners: always in range
+            for (int d = 0; d < 3; ++d) { out.pos[9 * t + 3 * k + d] = cPos[3 * c + d]; out.nrm[9 * t + 3 * k + d] = cNrm[3 * c + d]; }
+            out.uv[6 * t + 2 * k] = cUv[2 * c]; out.uv[6 * t + 2 * k + 1] = cUv[2 * c + 1];
         }
-    }
     return true;
 }
 

@@ -314,3 +314,52 @@ def test_q8_multi_object_obj_keeps_the_reference_index_bug_by_default(built, tmp
     fixed = tris()
     assert len(fixed) == 4 and fixed.count(first) == 1
     assert (5.0, 5.0, 5.0, 6.0, 5.0, 5.0, 5.0, 6.0, 5.0) in fixed and (9.0, 9.0, 9.0, 10.0, 9.0, 9.0, 9.0, 10.0, 9.0) in fixed
+
+
+def test_q8_with_quads_is_reproduced_corner_by_corner(built, tmp_path, monkeypatch):
+    """Q-8 at the level the reference has it (mesh.cpp:100-114 after aiProcess_Triangulate): Assimp's OBJ importer makes one vertex
+    per face CORNER, a quad's corners c..c+3 become the triangles (c, c+1, c+2), (c, c+2, c+3), and the reference appends each
+    aiMesh's LOCAL indices to one list over the CONCATENATED vertex arrays.  With quads in the file the triangles of the second
+    object are therefore built from corners of DIFFERENT faces of the first one -- not whole triangles of it, which is all a
+    triangles-only file can show.  Expected values come from a numpy restatement of exactly that indexing."""
+    from hobbyraytracer_amd import api
+    r = np.random.default_rng(5)
+    verts = r.uniform(-1, 1, (40, 3)).round(3)
+    lines = [f"v {a} {b} {c}" for a, b, c in verts]
+    # object a: quad, triangle, quad   (11 corners, 5 triangles); object b: triangle, quad, pentagon (12 corners, 6 triangles)
+    faces_a = [[1, 2, 3, 4], [5, 6, 7], [8, 9, 10, 11]]
+    faces_b = [[12, 13, 14], [15, 16, 17, 18], [19, 20, 21, 22, 23]]
+    lines += ["o a"] + ["f " + " ".join(map(str, f)) for f in faces_a] + ["o b"] + ["f " + " ".join(map(str, f)) for f in faces_b]
+    (tmp_path / "q.obj").write_text("\n".join(lines) + "\n")
+
+    def soup(quirk):
+        corners, tris, sub_first = [], [], []
+        for faces in (faces_a, faces_b):
+            sub_first.append(len(corners))
+            for f in faces:
+                c0 = len(corners)
+                corners += [verts[i - 1] for i in f]
+                tris += [(len(sub_first) - 1, c0, c0 + k, c0 + k + 1) for k in range(1, len(f) - 1)]
+        out = []
+        for sub, a, b, c in tris:
+            off = sub_first[sub] if quirk else 0          # mesh.cpp:111-114: local indices into the concatenated array
+            out.append([corners[a - off], corners[b - off], corners[c - off]])
+        return np.array(out, np.float32)
+
+    for env, quirk in ((None, True), ("rebased", False)):
+        if env: monkeypatch.setenv("HRT_OBJ_INDICES", env)
+        else: monkeypatch.delenv("HRT_OBJ_INDICES", raising=False)
+        y = tmp_path / "q.yaml"
+        y.write_text("film:\n    width: 8\n    height: 8\n    samples: 1\n    output: o.png\n"
+                     "camera:\n    position: [0, 0, 5]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 40\n    aperture: 0\n    focal_distance: 5\n"
+                     "    background: [0.5, 0.5, 0.5]\nmaterials:\n  - name: a\n    type: lambertian\n    albedo: [0.5, 0.5, 0.5]\n"
+                     "objects:\n  - type: mesh\n    path: q.obj\n    material: a\n")
+        hs = api.HostScene(str(y), str(tmp_path))
+        got = np.asarray(hs.mesh_arrays(0)[0], np.float32)
+        want = soup(quirk)
+        assert got.shape == want.shape == (11, 3, 3)
+        key = lambda t: tuple(np.round(t.reshape(-1), 5))     # (the BVH builder reorders the soup: compare as multisets of triangles)
+        assert sorted(map(key, got)) == sorted(map(key, want)), env
+    # with the quirk a triangle of object b mixes corners of two different faces of object a (corner 3 of the quad, corners 0 and 1 of the triangle)
+    q = soup(True)
+    assert np.array_equal(q[6], np.array([verts[3], verts[4], verts[5]], np.float32))
