@@ -1619,6 +1619,35 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         w.T = (unsigned)T;
         w.n_tasks = (unsigned)((n_slots + T - 1) / T);
         const int task_blocks = (int)std::min<size_t>(((size_t)w.n_tasks + 3) / 4, (size_t)sc->n_cus * 8);   // 4 waves = 4 tasks per block
+        // How many task groups.  Slot = sample x n_local + pixel, so the tasks of one image region recur every P = n_local / T
+        // tasks; group g owns the tasks g, g + G, g + 2G, ...: relative to the image its tasks DRIFT by d = (m P mod G, to the nearer
+        // multiple) per m samples, and unless that drift carries the group across the whole image within the batch's samples
+        // (d x samples / m >= P) a group sees the same part of the image in every sample, and the groups that own the mesh's
+        // pixels finish last.  251 is prime and drifts enough for the usual films -- but one rank's 536 rows of a 1920-wide film at
+        // T = 4096 have P = 251.25: d = 0.25, 128 tasks in 512 samples, half the image; that share ran 16 % slower than its 544-row
+        // sibling (58.2 against 50.3 ms: tests/tools/stripe_scaling.py c4).  So: 251 unless it resonates, then the next prime below
+        // that does not.
+        unsigned task_groups = HRT_TASK_GROUPS;
+        {
+            const double P = (double)n_local / (double)T;
+            auto covers = [&](unsigned G) {       // the smallest "fraction of the image a group gets to see", over m = 1..4
+                double worst = 1e30;
+                for (int m = 1; m <= 4; ++m) {
+                    const double r = std::fmod(m * P, (double)G), d = std::min(r, (double)G - r);
+                    worst = std::min(worst, d * (double)c / (m * P));
+                }
+                return worst;
+            };
+            if (P > 1.0 && c > 1 && covers(HRT_TASK_GROUPS) < 1.0) {
+                double best = -1.0;
+                for (unsigned G : {251u, 241u, 239u, 233u, 229u, 227u, 223u, 211u, 199u, 197u, 193u, 191u}) {
+                    const double v = covers(G);
+                    if (v >= 1.0) { task_groups = G; break; }
+                    if (v > best) { best = v; task_groups = G; }
+                }
+            }
+            if (const char* e = getenv("HRT_WF_TASK_GROUPS")) task_groups = (unsigned)std::min(256, std::max(1, atoi(e)));   // experiments
+        }
         // every launch of the batch gets its own zeroed block of "next task" counters
         unsigned* const ctr_base = sc->wf.buf.task_ctr;
         HIPCHK(hipMemsetAsync(ctr_base, 0, (wf_counter_words(D, n_mesh) + wf_ref_counter_words(D, n_mesh)) * sizeof(unsigned), stream));
@@ -1630,7 +1659,7 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
         const bool force_dynamic = getenv("HRT_WF_DYNAMIC_TASKS") != nullptr;   // tests: exercise the pull path on small tiles too
         auto next_counters = [&](unsigned waves) {
             w.task_ctr = ctr_base + 256 * launch_no++;
-            w.n_groups = std::min<unsigned>(HRT_TASK_GROUPS, waves);
+            w.n_groups = std::min<unsigned>(task_groups, waves);
             w.pull_k = (w.n_tasks <= waves && !force_dynamic) ? 0u : std::min(32u, std::max(1u, w.n_tasks / (waves * 4u)));
             w.group_q = w.n_tasks / w.n_groups; w.group_r = w.n_tasks % w.n_groups;
         };

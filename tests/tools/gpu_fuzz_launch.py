@@ -25,7 +25,7 @@ for name in ("teapot_scene", "three_meshes", "material_zoo", "cornell_box"):
 os.dup2(saved, 1)
 KNOBS = {"HRT_WF_MAX_SLOTS": [None, 64, 200, 1000, 4096, 50000], "HRT_WF_TASK_SIZE": [None, 64, 128, 256, 1024, 4096],
          "HRT_WF_TAIL_ROUND": [None, 1, 2, 3, 5, 9, 1000], "HRT_WF_DYNAMIC_TASKS": [None, 1], "HRT_EXT_BLOCKS_PER_CU": [None, 1, 2, 6, 10],
-         "HRT_EXT_LEAF_NUM": [None, 1, 16, 48, 64]}
+         "HRT_EXT_LEAF_NUM": [None, 1, 16, 48, 64], "HRT_WF_TASK_GROUPS": [None, 1, 7, 64, 191, 256]}
 bad = 0
 for it in range(N):
     name = list(scenes)[int(r.integers(0, len(scenes)))]
