@@ -1565,9 +1565,8 @@ hrt_status launch_wavefront(hrt_scene* sc, const hrt_camera* cam, const hrt_para
     size_t cap = wf_max_slots(sc);
     const int s_end = s_first + s_count;
     int chunk = (int)std::min<size_t>((size_t)s_count, std::max<size_t>(1, cap / n_local));
-    // equal batches: every batch pays the latency of its ~100 launches whatever its size, so the largest possible batches plus a
-    // small remainder (C4 on one GPU: 453 + 59 samples) cost what two of 256 do, and hold 77 % more memory
-    chunk = (s_count + (s_count + chunk - 1) / chunk - 1) / ((s_count + chunk - 1) / chunk);
+    // (the largest batches that fit plus a remainder, NOT equal batches: C4 on one GPU takes 92.8 ms as 453 + 59 samples and
+    //  97.1 ms as 256 + 256 -- a batch's rounds run the better the more paths they hold, round 3)
     hrt_status st;
     for (;;) {   // the memory estimate can be stale (other processes on the device): halve the batch on OOM
         const size_t slots = (size_t)n_local * chunk;
