@@ -295,3 +295,161 @@ objects:
     img, st = orc.World(hs.flat_ptr).render_tile(hs.camera(), api.default_params(24, 24, 64, quirks=api.QUIRKS_FIXED, max_depth=200))
     np.testing.assert_allclose(img.reshape(-1, 3).mean(0), [0.7, 0.5, 0.3], rtol=2e-3)
     assert np.abs(img - np.array([0.7, 0.5, 0.3], np.float32)).max() < 0.02
+
+
+def _scene_yaml(tmp_path, objects, name="s.yaml", extra_materials=""):
+    y = tmp_path / name
+    y.write_text("film:\n    width: 8\n    height: 8\n    samples: 1\n    output: o.png\n"
+                 "camera:\n    position: [0, 0, 9]\n    look_at: [0, 0, 0]\n    up: [0, 1, 0]\n    fov: 40\n    aperture: 0.001\n    focal_distance: 9\n    background: grey\n"
+                 "textures:\n  - name: grey\n    type: solid\n    colour: [0.5, 0.5, 0.5]\n"
+                 "materials:\n  - name: m\n    type: lambertian\n    albedo: [0.5, 0.5, 0.5]\n" + extra_materials + "objects:\n" + objects)
+    return str(y)
+
+
+def test_mesh_hits_against_float64_moeller_trumbore(built, assets, tmp_path):
+    """First principles, not the shared headers: world->hit of a mesh (mesh.cpp:43-46 -> bvh.cpp:69-78 -> triangle.cpp:57-131 with
+    the quirks off) against a float64 brute force over ALL triangles (Moeller-Trumbore, closest t > t_min).  20 000 rays at the
+    6200-triangle teapot: the same triangle (or a t equal to 1e-5 where two triangles share the hit, e.g. on an edge), the same t,
+    the interpolated normal of triangle.cpp:118-128 (un-normalised, faced against the ray) and uv.  Pins the oracle's tree build,
+    box test, watertight triangle test and attribute interpolation to geometry itself."""
+    import shutil
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as o
+    shutil.copy(f"{assets}/teapot.obj", tmp_path / "teapot.obj")
+    hs = api.HostScene(_scene_yaml(tmp_path, "  - type: mesh\n    path: teapot.obj\n    material: m\n"), str(tmp_path))
+    pos, nrm, uv = (np.asarray(a, np.float64) for a in hs.mesh_arrays(0))
+    n_tri = len(pos)
+    r = np.random.default_rng(77)
+    n_rays = 20000
+    org = r.uniform(-4, 4, (n_rays, 3)); org[:, 1] = r.uniform(-1, 4, n_rays)
+    tgt = r.uniform([-1.6, 0.0, -1.0], [1.4, 1.6, 1.0], (n_rays, 3))
+    dirs = (tgt - org) * r.uniform(0.2, 2.0, (n_rays, 1))
+    org32, dir32 = org.astype(np.float32), dirs.astype(np.float32)
+    hits = o.World(hs.flat_ptr).closest_hit(api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED), org32, dir32)
+    O, D = org32.astype(np.float64), dir32.astype(np.float64)
+    v0, e1, e2 = pos[:, 0], pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]
+    best_t = np.full(n_rays, np.inf); best_i = np.full(n_rays, -1); best_b = np.zeros((n_rays, 3)); margin = np.full(n_rays, np.inf)
+    for a in range(0, n_rays, 400):
+        o_, d_ = O[a:a + 400, None, :], D[a:a + 400, None, :]
+        pv = np.cross(d_, e2[None]); det = (e1[None] * pv).sum(-1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tv = o_ - v0[None]
+            u = (tv * pv).sum(-1) * inv
+            qv = np.cross(tv, e1[None])
+            v = (d_ * qv).sum(-1) * inv
+            t = (e2[None] * qv).sum(-1) * inv
+        w = 1.0 - u - v
+        edge = np.minimum(np.minimum(u, v), w)                 # > 0 inside; how far from the nearest edge (barycentric)
+        ok = (np.abs(det) > 1e-14) & (edge >= 0) & (t > 0.001)
+        tt = np.where(ok, t, np.inf)
+        i = tt.argmin(1); rows = np.arange(len(i))
+        best_t[a:a + 400] = tt[rows, i]; best_i[a:a + 400] = np.where(np.isfinite(tt[rows, i]), i, -1)
+        best_b[a:a + 400] = np.stack([w[rows, i], u[rows, i], v[rows, i]], 1)
+        # rays that pass within 1e-6 (barycentric) of ANY triangle's edge near the front are left out of the hit / miss comparison
+        near_edge = (np.abs(edge) < 1e-6) & (np.abs(det) > 1e-14) & (t > 0.001) & (t < tt[rows, i][:, None] * (1 + 1e-6) + 1e-9)
+        margin[a:a + 400] = np.where(near_edge.any(1), 0.0, 1.0)
+    clear = margin > 0
+    hit64 = best_i >= 0
+    got_hit = hits["prim"] >= 0
+    assert hit64.sum() > 8000 and (~hit64).sum() > 1000
+    assert np.array_equal(got_hit[clear], hit64[clear]), "hit / miss differs from the float64 brute force"
+    both = clear & hit64
+    np.testing.assert_allclose(hits["t"][both], best_t[both], rtol=2e-5, atol=1e-6)
+    same = hits["tri"][both] == best_i[both]
+    assert same.mean() > 0.999                                   # (the rest: two triangles met at the same t to 1e-5, checked by t above)
+    sel = np.where(both)[0][same]
+    b = best_b[sel]; ti = best_i[sel]
+    n_want = (b[:, :, None] * nrm[ti]).sum(1)
+    flip = (n_want * D[sel]).sum(1) > 0                          # hittable.h:21-24: against the ray
+    n_want[flip] *= -1
+    uv_want = (b[:, :, None] * uv[ti]).sum(1)
+    np.testing.assert_allclose(hits["normal"][sel], n_want, atol=3e-4)
+    np.testing.assert_allclose(np.stack([hits["u"][sel], hits["v"][sel]], 1), uv_want, atol=3e-4)
+    np.testing.assert_allclose(hits["p"][sel], O[sel] + best_t[sel, None] * D[sel], atol=3e-4)
+    assert np.array_equal(hits["front_face"][sel] == 1, ~flip)
+
+
+def test_analytic_primitives_against_float64(built, tmp_path):
+    """sphere.cpp:20-49, aarect.h:12-39 (and its two siblings), box.h:27-55 through the oracle's world->hit against float64
+    formulas written from the geometry: t, hit point, outward normal faced against the ray, and the u, v conventions
+    (sphere.cpp:4-18: phi = atan2(-z, x) + pi, theta = acos(-y); rects: (a - a0) / (a1 - a0))."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as o
+    r = np.random.default_rng(99)
+    n = 6000
+    org = r.uniform(-5, 5, (n, 3)).astype(np.float32)
+    cases = [
+        ("  - type: sphere\n    center: [0.3, -0.2, 0.5]\n    radius: 1.25\n    material: m\n", "sphere"),
+        ("  - type: xy_rect\n    x: [-1, 2]\n    y: [-0.5, 1.5]\n    k: 0.25\n    material: m\n", "xy"),
+        ("  - type: xz_rect\n    x: [-1, 2]\n    z: [-0.5, 1.5]\n    k: -0.75\n    material: m\n", "xz"),
+        ("  - type: yz_rect\n    y: [-1, 2]\n    z: [-0.5, 1.5]\n    k: 0.5\n    material: m\n", "yz"),
+        ("  - type: box\n    min: [-1, -0.5, -0.25]\n    max: [0.5, 1.0, 1.5]\n    material: m\n", "box"),
+    ]
+    for k, (yaml_obj, kind) in enumerate(cases):
+        hs = api.HostScene(_scene_yaml(tmp_path, yaml_obj, f"p{k}.yaml"), str(tmp_path))
+        tgt = r.uniform(-1.2, 1.6, (n, 3))
+        d32 = ((tgt - org) * r.uniform(0.3, 2.0, (n, 1))).astype(np.float32)
+        hits = o.World(hs.flat_ptr).closest_hit(api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED), org, d32)
+        O, D = org.astype(np.float64), d32.astype(np.float64)
+        t_w = np.full(n, np.inf); n_w = np.zeros((n, 3)); uv_w = np.zeros((n, 2)); graze = np.zeros(n, bool)
+        if kind == "sphere":
+            c, rad = np.array([0.3, -0.2, 0.5], np.float32).astype(np.float64), float(np.float32(1.25))
+            oc = O - c
+            a, hb, cc = (D * D).sum(1), (oc * D).sum(1), (oc * oc).sum(1) - rad * rad
+            disc = hb * hb - a * cc
+            graze = np.abs(disc) < 1e-3 * a * rad * rad
+            sq = np.sqrt(np.maximum(disc, 0))
+            t1, t2 = (-hb - sq) / a, (-hb + sq) / a
+            t = np.where(t1 >= 0.001, t1, t2)
+            ok = (disc > 0) & (t >= 0.001)
+            graze |= (np.abs(t1 - 0.001) < 1e-5) | (np.abs(t2 - 0.001) < 1e-5)
+            t_w = np.where(ok, t, np.inf)
+            P = O + t[:, None] * D
+            out = (P - c) / rad
+            n_w = out
+            uv_w = np.stack([(np.arctan2(-out[:, 2], out[:, 0]) + np.pi) / (2 * np.pi), np.arccos(np.clip(-out[:, 1], -1, 1)) / np.pi], 1)
+        else:
+            def rect(axis, a0, a1, b0, b1, kk):
+                ia, ib = [(1, 2), (0, 2), (0, 1)][axis]      # the two free axes, in the reference's member order
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = (kk - O[:, axis]) / D[:, axis]
+                A, B = O[:, ia] + t * D[:, ia], O[:, ib] + t * D[:, ib]
+                ok = (t >= 0.001) & (A >= a0) & (A <= a1) & (B >= b0) & (B <= b1)
+                gz = (np.abs(A - a0) < 1e-5) | (np.abs(A - a1) < 1e-5) | (np.abs(B - b0) < 1e-5) | (np.abs(B - b1) < 1e-5) | (np.abs(t - 0.001) < 1e-5)
+                nn = np.zeros((n, 3)); nn[:, axis] = 1.0
+                return np.where(ok, t, np.inf), nn, np.stack([(A - a0) / (a1 - a0), (B - b0) / (b1 - b0)], 1), gz & np.isfinite(t)
+            if kind == "xy": sides = [rect(2, -1, 2, -0.5, 1.5, 0.25)]
+            elif kind == "xz": sides = [rect(1, -1, 2, -0.5, 1.5, -0.75)]
+            elif kind == "yz": sides = [rect(0, -1, 2, -0.5, 1.5, 0.5)]
+            else:
+                mn, mx = np.array([-1, -0.5, -0.25]), np.array([0.5, 1.0, 1.5])
+                sides = []
+                for axis in range(3):
+                    ia, ib = [(1, 2), (0, 2), (0, 1)][axis]
+                    for kk in (mn[axis], mx[axis]):
+                        sides.append(rect(axis, mn[ia], mx[ia], mn[ib], mx[ib], kk))
+            ts = np.stack([s[0] for s in sides], 1)
+            i = ts.argmin(1); rows = np.arange(n)
+            t_w = ts[rows, i]
+            n_w = np.stack([s[1] for s in sides], 1)[rows, i]
+            uv_w = np.stack([s[2] for s in sides], 1)[rows, i]
+            graze = np.stack([s[3] for s in sides], 1).any(1)
+            srt = np.sort(ts, 1)
+            if ts.shape[1] > 1:                                       # box edges and corners: two sides at one t
+                with np.errstate(invalid="ignore"):
+                    graze |= np.isfinite(srt[:, 1]) & (np.abs(srt[:, 1] - srt[:, 0]) < 1e-5)
+        hit_w = np.isfinite(t_w)
+        ok = ~graze
+        assert hit_w[ok].sum() > 800, kind
+        assert np.array_equal(hits["prim"][ok] >= 0, hit_w[ok]), kind
+        sel = ok & hit_w
+        np.testing.assert_allclose(hits["t"][sel], t_w[sel], rtol=3e-5, atol=2e-6, err_msg=kind)
+        flip = (n_w * D).sum(1) > 0
+        n_f = np.where(flip[:, None], -n_w, n_w)
+        np.testing.assert_allclose(hits["normal"][sel], n_f[sel], atol=2e-4, err_msg=kind)
+        assert np.array_equal(hits["front_face"][sel] == 1, ~flip[sel]), kind
+        if True:
+            du = np.abs(hits["u"][sel] - uv_w[sel, 0]); du = np.minimum(du, 1 - du) if kind == "sphere" else du      # (u wraps at the seam)
+            assert du.max() < 3e-4 and np.abs(hits["v"][sel] - uv_w[sel, 1]).max() < 3e-4, kind
+        np.testing.assert_allclose(hits["p"][sel], (O + t_w[:, None] * D)[sel], atol=3e-4, err_msg=kind)
