@@ -948,6 +948,36 @@ int oracle_closest_hit(oracle_world* h, const hrt_params* pr, int64_t n, const f
     return 0;
 }
 
+// Material::scatter (material.h) at the first hit of n rays, for the statistical checks of the scatter distributions against
+// float64 (tests/test_oracle_kats.py): ray i draws as (pixel0 + i, sample 0, bounce 0).  flag: -1 miss, 0 scatter() returned
+// false (emitter, absorbed metal), 1 scattered.
+int oracle_scatter(oracle_world* h, const hrt_params* pr, int64_t n, const float* o, const float* d, uint32_t pixel0, float* out_dir,
+                   float* out_atten, int32_t* out_flag, hrt_hit* out_hit) {
+    g_quirks = pr->quirks;
+    g_ctx.seed_lo = pr->seed_lo; g_ctx.seed_hi = pr->seed_hi;
+    for (int64_t i = 0; i < n; ++i) {
+        g_ctx.pixel = pixel0 + (uint32_t)i; g_ctx.sample = 0; g_ctx.bounce = 0;
+        ray r(vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+        hitRecord rec; int prim;
+        out_flag[i] = -1;
+        for (int k = 0; k < 3; ++k) { out_dir[3 * i + k] = 0.0f; out_atten[3 * i + k] = 0.0f; }
+        hrt_hit hh = {};
+        hh.prim = -1; hh.tri = -1;
+        if (world_hit(*h->w, r, pr->t_min, std::numeric_limits<float>::infinity(), rec, prim)) {
+            hh.t = rec.t; hh.prim = prim; hh.tri = rec.tri; hh.front_face = rec.frontFace ? 1 : 0;
+            hh.p[0] = rec.p.x; hh.p[1] = rec.p.y; hh.p[2] = rec.p.z;
+            hh.normal[0] = rec.normal.x; hh.normal[1] = rec.normal.y; hh.normal[2] = rec.normal.z;
+            ray scattered; vec3 attenuation(0, 0, 0);
+            const bool ok = rec.matPtr->scatter(r, rec, attenuation, scattered);
+            out_flag[i] = ok ? 1 : 0;
+            if (ok) { out_dir[3 * i] = scattered.dir.x; out_dir[3 * i + 1] = scattered.dir.y; out_dir[3 * i + 2] = scattered.dir.z; }
+            out_atten[3 * i] = attenuation.x; out_atten[3 * i + 1] = attenuation.y; out_atten[3 * i + 2] = attenuation.z;
+        }
+        if (out_hit) out_hit[i] = hh;
+    }
+    return 0;
+}
+
 // Debug aid for the parity tests: the segments of ONE path (pixel pIdx, sample s): per segment 6 floats
 // (ray o, d) and 3 values (prim, tri, t).  Returns the number of segments written (<= max_seg).
 int oracle_trace_path(oracle_world* h, const hrt_camera* cam, const hrt_params* pr, int pIdx, int s, int max_seg, float* rays, float* hits) {

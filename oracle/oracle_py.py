@@ -31,6 +31,7 @@ _lib.oracle_world_create.restype = _vp
 _lib.oracle_world_destroy.argtypes = [_vp]
 _lib.oracle_world_destroy.restype = None
 _lib.oracle_render_tile.argtypes = [_vp, C.POINTER(api.Camera), C.POINTER(api.Params), api.Rect, _fp, C.POINTER(api.Stats), C.c_int]
+_lib.oracle_scatter.argtypes = [_vp, C.POINTER(api.Params), C.c_int64, _fp, _fp, C.c_uint32, _fp, _fp, C.POINTER(C.c_int32), C.POINTER(api.Hit)]
 _lib.oracle_closest_hit.argtypes = [_vp, C.POINTER(api.Params), C.c_int64, _fp, _fp, C.c_float, C.c_float, C.c_uint32, C.POINTER(api.Hit)]
 _lib.oracle_resolve_u8.argtypes = [_fp, C.c_int64, C.POINTER(C.c_uint8)]
 _lib.oracle_resolve_u8.restype = None
@@ -90,6 +91,17 @@ class World:
         out = np.zeros(n, dtype=api.HIT_DTYPE)
         _lib.oracle_closest_hit(self._h, C.byref(params), n, _p(o), _p(d), t_min, t_max, pixel0, out.ctypes.data_as(C.POINTER(api.Hit)))
         return out
+
+    def scatter(self, params, origins, dirs, pixel0=0):
+        """Material::scatter at the first hit of every ray: (scattered directions (n, 3), attenuations (n, 3), flags (n): -1 miss /
+        0 not scattered / 1 scattered, hit records)."""
+        o, d = _f32(origins), _f32(dirs)
+        n = o.shape[0]
+        out_d = np.zeros((n, 3), np.float32); out_a = np.zeros((n, 3), np.float32); flag = np.zeros(n, np.int32)
+        hits = np.zeros(n, dtype=api.HIT_DTYPE)
+        _lib.oracle_scatter(self._h, C.byref(params), n, _p(o), _p(d), pixel0, _p(out_d), _p(out_a), flag.ctypes.data_as(C.POINTER(C.c_int32)),
+                            hits.ctypes.data_as(C.POINTER(api.Hit)))
+        return out_d, out_a, flag, hits
 
 
 _lib.oracle_trace_path.argtypes = [_vp, C.POINTER(api.Camera), C.POINTER(api.Params), C.c_int, C.c_int, C.c_int, _fp, _fp]

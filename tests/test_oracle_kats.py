@@ -453,3 +453,78 @@ def test_analytic_primitives_against_float64(built, tmp_path):
             du = np.abs(hits["u"][sel] - uv_w[sel, 0]); du = np.minimum(du, 1 - du) if kind == "sphere" else du      # (u wraps at the seam)
             assert du.max() < 3e-4 and np.abs(hits["v"][sel] - uv_w[sel, 1]).max() < 3e-4, kind
         np.testing.assert_allclose(hits["p"][sel], (O + t_w[:, None] * D)[sel], atol=3e-4, err_msg=kind)
+
+
+def test_scatter_distributions_against_float64(built, tmp_path):
+    """Material::scatter (material.h:132-242) through the oracle, against what the formulas say in float64 -- nothing shared with
+    hrt_glm.h / hrt_rng.h but the uniform draws themselves:
+      Lambertian (material.h:137-153): direction = n + sphericalRand(1) -- a cosine lobe about n: E[cos] = 2/3, E[cos^2] = 1/2, azimuth uniform;
+      Metal, roughness 0 (material.h:166-177): the mirror direction (+ glm::epsilon), attenuation = albedo;
+      Dielectric, roughness 0 (material.h:204-229): reflected with Schlick's probability (material.h:236-241, with the refraction RATIO
+        where a refractive index is meant, as the reference has it), refracted by Snell's law otherwise; from inside, beyond the critical
+        angle, always reflected."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as o
+    mats = ("  - name: mirror\n    type: metal\n    albedo: [0.9, 0.6, 0.3]\n    roughness: 0.0\n"
+            "  - name: glass\n    type: dielectric\n    ior: 1.5\n    roughness: 0.0\n")
+    rect = "  - type: xy_rect\n    x: [-50, 50]\n    y: [-50, 50]\n    k: 0\n    material: %s\n"
+    p = api.default_params(8, 8, 1, quirks=api.QUIRKS_FIXED, seed=3)
+    n = 200000
+    r = np.random.default_rng(4)
+
+    def rays(theta_deg, from_above=True):
+        th = np.radians(theta_deg)
+        d = np.array([np.sin(th), 0.0, -np.cos(th) if from_above else np.cos(th)])
+        org = np.stack([r.uniform(-5, 5, n), r.uniform(-5, 5, n), np.full(n, 2.0 if from_above else -2.0)], 1)
+        return org.astype(np.float32), np.tile((d * 1.7).astype(np.float32), (n, 1))      # un-normalised, as the path tracer's
+
+    # ---- Lambertian
+    hs = api.HostScene(_scene_yaml(tmp_path, rect % "m", "lam.yaml"), str(tmp_path))
+    org, d = rays(35.0)
+    sd, att, flag, hits = o.World(hs.flat_ptr).scatter(p, org, d)
+    assert (flag == 1).all() and np.allclose(att, 0.5)
+    assert np.allclose(hits["normal"], [0, 0, 1])                                        # faced against the ray (coming from +z)
+    u = sd.astype(np.float64); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    cos = u[:, 2]
+    assert (cos > -1e-6).all()
+    assert abs(cos.mean() - 2 / 3) < 3e-3 and abs((cos ** 2).mean() - 0.5) < 3e-3        # pdf(cos) = 2 cos
+    phi = np.arctan2(u[:, 1], u[:, 0])
+    hist, _ = np.histogram(phi, bins=16, range=(-np.pi, np.pi))
+    assert np.abs(hist / hist.mean() - 1).max() < 0.03
+    # the un-normalised direction is n + a unit vector: |sd - n| = 1
+    np.testing.assert_allclose(np.linalg.norm(sd.astype(np.float64) - [0, 0, 1], axis=1), 1.0, atol=5e-6)
+
+    # ---- Metal, roughness 0
+    hs = api.HostScene(_scene_yaml(tmp_path, rect % "mirror", "met.yaml", mats), str(tmp_path))
+    for theta in (0.0, 20.0, 60.0, 85.0):
+        org, d = rays(theta)
+        sd, att, flag, _ = o.World(hs.flat_ptr).scatter(p, org[:2000], d[:2000])
+        assert (flag == 1).all() and np.allclose(att, [0.9, 0.6, 0.3])
+        di = d[0].astype(np.float64); di /= np.linalg.norm(di)
+        want = di - 2 * di[2] * np.array([0, 0, 1.0]) + np.finfo(np.float32).eps
+        np.testing.assert_allclose(sd, np.tile(want, (2000, 1)), atol=3e-7)
+
+    # ---- Dielectric, roughness 0: entering (front face, ratio 1 / 1.5) and leaving (back face, ratio 1.5)
+    hs = api.HostScene(_scene_yaml(tmp_path, rect % "glass", "die.yaml", mats), str(tmp_path))
+    w = o.World(hs.flat_ptr)
+    for from_above, ratio in ((True, 1 / 1.5), (False, 1.5)):
+        for theta in (0.0, 30.0, 40.0, 60.0, 80.0):
+            org, d = rays(theta, from_above)
+            sd, att, flag, hits = w.scatter(p, org, d)
+            assert (flag == 1).all() and np.allclose(att, 1.0)
+            assert (hits["front_face"] == (1 if from_above else 0)).all()
+            cos_t = np.cos(np.radians(theta)); sin_t = np.sin(np.radians(theta))
+            side = -1.0 if from_above else 1.0                     # the refracted ray keeps going in the incoming z direction
+            reflected = np.sign(sd[:, 2]) != side
+            if ratio * sin_t > 1.0:
+                assert reflected.all()                             # total internal reflection (material.h:218)
+                continue
+            r0 = ((1 - ratio) / (1 + ratio)) ** 2
+            schlick = r0 + (1 - r0) * (1 - cos_t) ** 5
+            assert abs(reflected.mean() - schlick) < 4 * np.sqrt(schlick * (1 - schlick) / n) + 1e-4, (from_above, theta, reflected.mean(), schlick)
+            t = sd[~reflected].astype(np.float64)
+            np.testing.assert_allclose(np.linalg.norm(t, axis=1), 1.0, atol=5e-6)                   # glm::refract of a unit vector is a unit vector
+            np.testing.assert_allclose(np.hypot(t[:, 0], t[:, 1]), ratio * sin_t, atol=5e-6)        # Snell
+            m = sd[reflected].astype(np.float64)
+            if len(m):
+                np.testing.assert_allclose(m, np.tile([sin_t, 0.0, -side * cos_t], (len(m), 1)), atol=5e-6)
