@@ -513,6 +513,33 @@ def test_full_size_bust_hit_records_and_small_film(built, assets_full, scenes_di
     dev.close()
 
 
+def test_bust_on_a_deep_tree_runs_the_32_entry_stack_kernels(built, assets_full, scenes_dir, monkeypatch):
+    """BASELINE's C5 names a "deep-BVH LDS-stack stress": the host's SAH tree of the 100 k-triangle bust is 18 levels deep (the 20-entry
+    stack), so the stress is made here -- the same mesh on its Morton LBVH from the GPU, 29 levels deep: k_wf_ext / k_wf_tail with the
+    32-entry stack (4 instead of 6 blocks per CU) and the megakernel, both quirk sets, film and segment counts against the oracle."""
+    from hobbyraytracer_amd import api
+    from oracle import oracle_py as orc
+    api.use_device_bvh_builder(True, algo="lbvh")
+    try:
+        hs = api.HostScene(f"{scenes_dir}/bust_scene.yaml", assets_full)
+    finally:
+        api.use_device_bvh_builder(False)
+    depth = max(hs.bvh_depth(m) for m in range(hs.flat.n_meshes))
+    assert hs.flat.n_tris > 95_000 and 25 <= depth <= 31, depth
+    dev, world = api.DeviceScene(hs.flat_ptr, 0), orc.World(hs.flat_ptr)
+    W, H, spp = 96, 96, 6
+    cam = hs.camera(W, H)
+    for q in (api.QUIRKS_REFERENCE, api.QUIRKS_FIXED):
+        ref, sr = world.render_tile(cam, api.default_params(W, H, spp, quirks=q, stats=True))
+        assert sr.mesh_hits > 8000
+        for tail, mega in (("1000", False), ("2", False), ("1", True)):
+            monkeypatch.setenv("HRT_WF_TAIL_ROUND", tail)
+            img, st = dev.render_tile(cam, api.default_params(W, H, spp, quirks=q, stats=True, megakernel=mega))
+            assert (st.rays, st.mesh_hits) == (sr.rays, sr.mesh_hits), (q, tail, mega)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (q, tail, mega)
+    dev.close()
+
+
 def test_thin_lens_flag_on_every_render_path(built, assets, scenes_dir, monkeypatch):
     """HRT_FLAG_THIN_LENS (camera.h:34's commented-out circularRand(lensRadius), hrt.h hrt_camera): pipeline, tail and megakernel
     equal the oracle; the CPU twin (test_flat_vs_oracle_cpu.py) checks what the flag means."""
