@@ -37,7 +37,7 @@ extern "C" __attribute__((visibility("hidden"))) void hrt_set_last_error(const c
 
 namespace {
 
-#define HRT_SAH_SMALL 128u
+#define HRT_SAH_SMALL 64u
 #define HRT_SAH_CHUNK 1024u
 #define HRT_SAH_BINS 16
 #define HRT_SAH_LEVELS 31              // SahBuilder::sahLevels
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_sah_scatter(const Work* __restrict__ wo
 }
 
 // One WAVE per small subtree: SahBuilder::build with an explicit stack, the 64 lanes sharing each node's passes over its
-// triangles (at most two per lane).  The subtree's refs are copied into LDS once; `lidx` is the wave's private index array
+// triangles (HRT_SAH_SMALL / 64 per lane; the partition below holds two per lane in registers: HRT_SAH_SMALL <= 128).  The subtree's refs are copied into LDS once; `lidx` is the wave's private index array
 // (positions into that copy), permuted in place and written back to idx[lo, hi) at the end.
 #define HRT_SAH_WAVES 4
 struct SmallLds {
