@@ -301,7 +301,7 @@ def test_progress_counter_and_the_reporter_thread(built, assets, scenes_dir, tmp
     import time
     from hobbyraytracer_amd import api
     hs = api.HostScene(f"{scenes_dir}/teapot_scene.yaml", assets)
-    W, H, spp = 256, 256, 64
+    W, H, spp = 384, 384, 100             # ~20 ms of rendering: the poller below sees a dozen intermediate values
     cam = hs.camera(W, H)
     dev = api.DeviceScene(hs.flat_ptr, 0)
     assert dev.progress() == (0, 0)
