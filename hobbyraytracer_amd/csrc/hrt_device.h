@@ -692,6 +692,29 @@ __device__ inline void trav_inner(const uint4* __restrict__ nodes, const MeshRay
     const int cur = ts.cur;
     const uint4 A = nodes[2 * cur + 0];
     const uint4 B = nodes[2 * cur + 1];
+#if defined(HRT_TA_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    // experiment (tests/tools/ta_probe.sh): HRT_TA_PROBE more 16-byte loads of the same record per node step, results unused -- the
+    // same cache line, no longer dependency chain (the step waits for A and B anyway), only more lane-accesses for the L1's
+    // address / tag pipeline: if the kernel's time follows, that pipeline is what bounds it
+    {
+        const uint4* pp = nodes + 2 * cur;
+        uint4 X;
+#pragma unroll
+        for (int k_ = 0; k_ < HRT_TA_PROBE; ++k_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(X) : "v"(pp), "n"(16 * (k_ & 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(X.x));
+    }
+#endif
+#if defined(HRT_VALU_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    // experiment (tests/tools/ta_probe.sh): HRT_VALU_PROBE more vector instructions per node step (independent v_fma on two scratch
+    // registers): how much of an issue slot's worth of time does the kernel pay for an instruction?
+    {
+        float p0_ = 1.0f, p1_ = 2.0f;
+#pragma unroll
+        for (int k_ = 0; k_ < HRT_VALU_PROBE / 2; ++k_) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(p0_)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(p1_)); }
+        asm volatile("" :: "v"(p0_), "v"(p1_));
+    }
+#endif
 #ifdef HRT_STEP_PROFILE      // experiments: where a node step's cycles go (s_memtime after forced waits; see tests/tools/step_profile_run.py)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     { const unsigned long long n_ = __builtin_readcyclecounter(); stp[0] += n_ - stp[3]; stp[3] = n_; stp[6] += 1; }
