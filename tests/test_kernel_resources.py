@@ -65,3 +65,13 @@ def test_tail_kernel_keeps_four_blocks_per_cu(usage):
         for name, u in _find(usage, frag).items():
             assert u["VGPRs"] <= 128 and u["ScratchSize"] <= 16, (name, u)
             assert 4 * u["LDS"] <= 160 * 1024, (name, u)
+
+
+def test_instrumented_builds_still_compile():
+    """The diagnostic builds (-DHRT_DEBUG_BOUNDS: tests/tools/debug_bounds.sh; -DHRT_TA_PROBE / -DHRT_VALU_PROBE: tests/tools/ta_probe.sh)
+    are not part of the product build: a syntax-only pass keeps them from rotting."""
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
+           "-DHRT_DEBUG_BOUNDS", "-DHRT_TA_PROBE=1", "-DHRT_VALU_PROBE=2", "-fsyntax-only",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "hobbyraytracer_amd", "csrc", "hrt_hip.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
