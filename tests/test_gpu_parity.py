@@ -302,3 +302,29 @@ def test_headline_frame_at_full_size_against_the_oracle(built, tmp_path):
         same = (out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref))
         assert same.all() and rays == sr.rays, (G, int((~same).any(2).sum()), rays)
     dev.close()
+
+
+def test_kernel_films_equal_the_committed_fixtures(built, tmp_path, monkeypatch):
+    """The kernels against tests/golden/films.npz (the oracle's films as committed at the end of round 3, see
+    tests/golden/make_film_fixtures.py): bit for bit, pipeline and megakernel -- the GPU half of the guard against a common-mode edit
+    of the shared glm / libm / RNG restatement."""
+    import importlib.util
+    from hobbyraytracer_amd import api
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_film_fixtures", os.path.join(here, "golden", "make_film_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    mk.assets(str(tmp_path))
+    want = np.load(os.path.join(here, "golden", "films.npz"))
+    for scene, W, H, spp in mk.CASES:
+        hs = api.HostScene(os.path.join(here, "golden", "scenes", scene), str(tmp_path))
+        dev = api.DeviceScene(hs.flat_ptr, 0)
+        cam = hs.camera(W, H)
+        for qn, q in (("ref", api.QUIRKS_REFERENCE), ("fixed", api.QUIRKS_FIXED)):
+            key = f"{scene.split('.')[0]}_{qn}"
+            for mega in (False, True):
+                img, st = dev.render_tile(cam, api.default_params(W, H, spp, quirks=q, seed=11, stats=True, megakernel=mega))
+                b = want[key]
+                same = (img.view(np.uint32) == b.view(np.uint32)) | (np.isnan(img) & np.isnan(b))
+                assert same.all(), (key, mega, int((~same).sum()))
+                assert [st.rays, st.mesh_hits] == want[key + "_rays"].tolist(), (key, mega)
+        dev.close()

@@ -3,6 +3,8 @@
 and the quantisation rule of film.cpp:27-29; plus the restated glm semantics (quaternion, distributions)
 and the published Philox4x32-10 known-answer vectors.  Everything else the oracle computes is "parity
 unpinned" (no reference output exists): see DESIGN.md."""
+import os
+
 import numpy as np
 import pytest
 
@@ -528,3 +530,23 @@ def test_scatter_distributions_against_float64(built, tmp_path):
             m = sd[reflected].astype(np.float64)
             if len(m):
                 np.testing.assert_allclose(m, np.tile([sin_t, 0.0, -side * cos_t], (len(m), 1)), atol=5e-6)
+
+
+def test_oracle_films_equal_the_committed_fixtures(built, tmp_path):
+    """tests/golden/films.npz (written by tests/golden/make_film_fixtures.py at the end of round 3): the oracle's films of the seven
+    committed scenes, both quirk sets, bit for bit.  Oracle and kernels share the glm / libm / RNG restatement (hrt_glm.h, hrt_rng.h):
+    an edit there would move both together and leave every GPU-vs-oracle test green; this is the test that goes red."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_film_fixtures", os.path.join(os.path.dirname(__file__), "golden", "make_film_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    mk.assets(str(tmp_path))
+    got = mk.render_all(str(tmp_path))
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "films.npz"))
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        a, b = got[k], want[k]
+        if a.dtype == np.float32:
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (k, int((~same).sum()))
+        else:
+            assert np.array_equal(a, b), k
